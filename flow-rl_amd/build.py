@@ -1,0 +1,80 @@
+"""Build libflowrl_hip.so (gfx950) in-tree with hipcc.
+
+    python flow-rl_amd/build.py [--force] [--jobs N]
+
+Cross-compiles without a GPU.  Output: flow-rl_amd/flowrl_hip/libflowrl_hip.so (git-ignored, but it
+travels to the GPU box with the tree).  Objects are cached under flow-rl_amd/csrc/_obj/ and rebuilt
+when a source or header is newer.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+CSRC = HERE / "csrc"
+OBJ = CSRC / "_obj"
+OUT = HERE / "flowrl_hip" / "libflowrl_hip.so"
+ARCH = "gfx950"
+SOURCES = ["capi.hip", "prepare.hip", "sampler_g32.hip"]
+HEADERS = [CSRC / "frl_internal.h", ROOT / "include" / "flowrl_hip.h"]
+FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++17", "-Wno-unused-value",
+         f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (ROCm toolchain required to build libflowrl_hip.so)")
+    return exe
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
+    OBJ.mkdir(parents=True, exist_ok=True)
+    cc = hipcc()
+    todo = []
+    objs = []
+    for src in SOURCES:
+        s = CSRC / src
+        o = OBJ / (s.stem + ".o")
+        objs.append(o)
+        if force or _stale(o, [s, *HEADERS, Path(__file__)]):
+            todo.append((s, o))
+
+    def compile_one(so):
+        s, o = so
+        cmd = [cc, *FLAGS, "-c", str(s), "-o", str(o)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(compile_one, todo))
+    if force or todo or _stale(OUT, objs):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(OUT)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=4)
+    args = ap.parse_args()
+    print(build(force=args.force, jobs=args.jobs))
+    sys.exit(0)

@@ -1,0 +1,177 @@
+// C ABI of libflowrl_hip.so (include/flowrl_hip.h): validation, planning, kernel dispatch.
+// Enqueue-only: no allocation, no host synchronisation, no retained pointers.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "frl_internal.h"
+
+namespace frl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int validate_desc(const FrlDesc* d) {
+  if (d == nullptr) { set_error("desc is NULL"); return FRL_EINVAL; }
+  if (d->abi_version != FRL_ABI_VERSION) { set_error("desc.abi_version %d != library %d", d->abi_version, FRL_ABI_VERSION); return FRL_EINVAL; }
+  if (d->kind < FRL_KIND_DDPM || d->kind > FRL_KIND_CNF) { set_error("desc.kind %d invalid", d->kind); return FRL_EINVAL; }
+  if (d->kind == FRL_KIND_CNF) {
+    if (d->solver != FRL_SOLVER_EULER) { set_error("CNF sampler supports solver EULER only (cnf.py:92-111)"); return FRL_EINVAL; }
+  } else if (d->solver != FRL_SOLVER_DDPM && d->solver != FRL_SOLVER_DDIM) {
+    set_error("solver %d not supported for kind %d (ddpm / ddim only; dpm2 and dpm++2m fall back to the host path)", d->solver, d->kind);
+    return d->solver == FRL_SOLVER_EULER ? FRL_EINVAL : FRL_EUNSUPPORTED;
+  }
+  if (d->steps < 1 || d->steps > 256) { set_error("desc.steps %d outside [1, 256]", d->steps); return FRL_EINVAL; }
+  if (d->n_states < 0 || d->particles < 1) { set_error("n_states %lld / particles %d invalid", (long long)d->n_states, d->particles); return FRL_EINVAL; }
+  if ((long long)d->n_states * d->particles > (1LL << 31) - 1 - 256) { set_error("more than 2^31 chains in one call"); return FRL_EINVAL; }
+  if (d->x_dim < 1) { set_error("x_dim %d invalid", d->x_dim); return FRL_EINVAL; }
+  if (d->cond_dim < 0) { set_error("cond_dim %d invalid", d->cond_dim); return FRL_EINVAL; }
+  if (d->time_embed < FRL_TEMB_NONE || d->time_embed > FRL_TEMB_FOURIER) { set_error("time_embed %d invalid", d->time_embed); return FRL_EINVAL; }
+  if (d->time_embed != FRL_TEMB_NONE && (d->time_dim < 4 || (d->time_dim & 1))) { set_error("time_dim %d must be even and >= 4", d->time_dim); return FRL_EINVAL; }
+  if (d->n_hidden < 1 || d->n_hidden > FRL_MAX_HIDDEN) { set_error("n_hidden %d outside [1, %d]", d->n_hidden, FRL_MAX_HIDDEN); return FRL_EINVAL; }
+  for (int l = 0; l < d->n_hidden; ++l)
+    if (d->hidden[l] < 1) { set_error("hidden[%d] = %d invalid", l, d->hidden[l]); return FRL_EINVAL; }
+  if (d->act < FRL_ACT_MISH || d->act > FRL_ACT_ELU) { set_error("act %d invalid", d->act); return FRL_EINVAL; }
+  if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
+  if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
+  // --- what this build has kernels for ---
+  if (d->dtype != FRL_DTYPE_F32) { set_error("bf16 MFMA variant not built yet"); return FRL_EUNSUPPORTED; }
+  for (int l = 0; l < d->n_hidden; ++l)
+    if (d->hidden[l] != G32_H) { set_error("hidden width %d: only %d-wide MLPs have a kernel in this build", d->hidden[l], G32_H); return FRL_EUNSUPPORTED; }
+  if (d->x_dim > LAST_PAD) { set_error("x_dim %d > %d", d->x_dim, LAST_PAD); return FRL_EUNSUPPORTED; }
+  return FRL_OK;
+}
+
+static int check_ws(const Plan& pl, const void* ws, size_t bytes) {
+  if (ws == nullptr) { set_error("workspace is NULL"); return FRL_EWORKSPACE; }
+  if (((uintptr_t)ws & 255) != 0) { set_error("workspace must be 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (bytes < pl.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B", bytes, pl.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  return FRL_OK;
+}
+
+}  // namespace frl
+
+using namespace frl;
+
+extern "C" {
+
+int frl_abi_version(void) { return FRL_ABI_VERSION; }
+
+const char* frl_last_error(void) { return g_err; }
+
+int frl_validate(const FrlDesc* desc) { return validate_desc(desc); }
+
+size_t frl_workspace_bytes(const FrlDesc* desc) {
+  if (validate_desc(desc) != FRL_OK) return 0;
+  Plan pl;
+  plan_from_desc(*desc, pl);
+  return pl.total_floats * sizeof(float);
+}
+
+double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
+  if (desc == nullptr || desc->n_hidden < 1 || desc->n_hidden > FRL_MAX_HIDDEN) return 0.0;
+  const double B = (double)desc->n_states * desc->particles, T = desc->steps;
+  const int A = desc->x_dim, C = desc->cond_dim;
+  const int Dp = desc->time_embed == FRL_TEMB_NONE ? 1 : desc->time_dim;
+  double macs = (double)(A + Dp + C) * desc->hidden[0];
+  for (int l = 1; l < desc->n_hidden; ++l) macs += (double)desc->hidden[l - 1] * desc->hidden[l];
+  macs += (double)desc->hidden[desc->n_hidden - 1] * A;
+  if (executed != nullptr) {
+    Plan pl;
+    plan_from_desc(*desc, pl);
+    double em = (double)(pl.XR + 2 * pl.CK) * pl.H;             // Dense_0 without the hoisted time slice, padded
+    for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
+    em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
+    *executed = 2.0 * B * T * em;
+  }
+  return 2.0 * B * T * macs;
+}
+
+int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                        void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = validate_desc(desc);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr) { set_error("params is NULL"); return FRL_EINVAL; }
+  Plan pl;
+  plan_from_desc(*desc, pl);
+  rc = check_ws(pl, workspace, workspace_bytes);
+  if (rc != FRL_OK) return rc;
+  for (int l = 0; l <= desc->n_hidden; ++l)
+    if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->time_embed != FRL_TEMB_NONE) {
+    for (int k = 0; k < 2; ++k)
+      if (params->tmlp_kernel[k] == nullptr || params->tmlp_bias[k] == nullptr) { set_error("params.tmlp_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+    if (desc->time_embed == FRL_TEMB_FOURIER && params->time_kernel == nullptr) { set_error("params.time_kernel is NULL"); return FRL_EINVAL; }
+  }
+  FrlSchedule s;
+  memset(&s, 0, sizeof(s));
+  if (desc->kind != FRL_KIND_CNF) {
+    if (sched == nullptr) { set_error("sched is NULL"); return FRL_EINVAL; }
+    s = *sched;
+    if (s.alphas == nullptr || s.alpha_hats == nullptr) { set_error("sched.alphas / alpha_hats is NULL"); return FRL_EINVAL; }
+    if (desc->kind == FRL_KIND_DDPM && desc->solver == FRL_SOLVER_DDPM && s.postvars == nullptr) { set_error("sched.postvars is NULL"); return FRL_EINVAL; }
+    if (desc->kind == FRL_KIND_CDDPM && (s.ts == nullptr || s.betas == nullptr)) { set_error("sched.ts / betas is NULL"); return FRL_EINVAL; }
+  }
+  PArgs pa;
+  pa.p = *params;
+  pa.s = s;
+  pa.ws = (float*)workspace;
+  pa.plan = pl;
+  pa.kind = desc->kind;
+  pa.time_embed = desc->time_embed;
+  return launch_prepare(pa, (hipStream_t)hip_stream);
+}
+
+int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
+                    const void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = validate_desc(desc);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
+  Plan pl;
+  plan_from_desc(*desc, pl);
+  rc = check_ws(pl, workspace, workspace_bytes);
+  if (rc != FRL_OK) return rc;
+  if (pl.B == 0) return FRL_OK;   // empty batch: nothing to do (reference returns empty arrays)
+  if (bufs->xT == nullptr || bufs->x0 == nullptr) { set_error("bufs.xT / x0 is NULL"); return FRL_EINVAL; }
+  if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
+  const bool needs_noise = (desc->kind != FRL_KIND_CNF) && desc->solver == FRL_SOLVER_DDPM;
+  if (needs_noise && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step"); return FRL_EINVAL; }
+  if (desc->want_history && (bufs->xt_hist == nullptr || bufs->eps_hist == nullptr)) { set_error("want_history set but xt_hist / eps_hist is NULL"); return FRL_EINVAL; }
+  for (int l = 1; l < desc->n_hidden; ++l)
+    if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+
+  const float* ws = (const float*)workspace;
+  KArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xT = bufs->xT; a.cond = bufs->cond; a.noise = needs_noise ? bufs->noise : nullptr;
+  a.x0 = bufs->x0;
+  a.xt_hist = desc->want_history ? bufs->xt_hist : nullptr;
+  a.eps_hist = desc->want_history ? bufs->eps_hist : nullptr;
+  for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
+  a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
+  a.ws_wlp = ws + pl.off_wlp; a.ws_blp = ws + pl.off_blp;
+  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L;
+  a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
+  a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
+  return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
+}
+
+int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                    const FrlFwdBufs* bufs, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = frl_sampler_prepare(desc, params, sched, workspace, workspace_bytes, hip_stream);
+  if (rc != FRL_OK) return rc;
+  return frl_sampler_run(desc, params, bufs, workspace, workspace_bytes, hip_stream);
+}
+
+int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream) {
+  if (A == nullptr || B == nullptr || D == nullptr || K < 2 || (K & 1)) { set_error("selftest: bad arguments"); return FRL_EINVAL; }
+  return launch_selftest_mfma32(A, B, D, K, (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

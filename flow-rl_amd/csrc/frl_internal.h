@@ -1,0 +1,105 @@
+// Internal definitions shared by the HIP translation units of libflowrl_hip.so.
+// Not part of the public ABI (that is include/flowrl_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "flowrl_hip.h"
+
+namespace frl {
+
+// ---- geometry "G32": exact-f32 MFMA 32x32x2, one wave owns 32 chains, hidden width 256 ------------
+constexpr int G32_H = 256;            // hidden width this geometry is built for
+constexpr int G32_CHAINS = 32;        // chains (MFMA columns) per wave
+constexpr int SLAB_BYTES = 32768;     // one weight K-slab in LDS: 32 rows x 256 f32
+constexpr int SLAB_ROWS = 32;
+constexpr int NBUF = 2;               // LDS slab ring depth
+constexpr int COEF_STRIDE = 8;        // floats per step in the coefficient table
+constexpr int MAX_WAVES = 4;          // waves per workgroup (one per SIMD)
+constexpr int LAST_PAD = 32;          // last layer is zero-padded to 32 output rows (one MFMA block)
+
+// per-step update modes (ws coef table is built for exactly one of them)
+enum Mode : int {
+  MODE_DDPM_DDPM = 0,   // ddpm.py:198-206
+  MODE_DDPM_DDIM = 1,   // ddpm.py:207-213
+  MODE_CDDPM_DDPM = 2,  // continuous_ddpm.py:165-174
+  MODE_CDDPM_DDIM = 3,  // continuous_ddpm.py:165-166,176-177
+  MODE_CNF_EULER = 4,   // cnf.py:108-110
+};
+
+// Derived sizes of one call (host + device agree through this one function).
+struct Plan {
+  int A, C, D, Dp;      // action dim, cond dim, time_dim, D' (= D or 1) rows of Dense_0 taken by time
+  int H, L, T;
+  int XR;               // layer-0 x rows in the packed image: 8*ceil(A/8) (pairs (a, a+4) per k-step)
+  int AR;               // x registers per lane = XR/2
+  int CK;               // layer-0 cond k-steps = ceil(C/2)
+  int K0p;              // rows of the packed layer-0 image = XR + 2*CK
+  int merged;           // 1: x rows and cond rows share ONE slab (K0p <= 32)
+  int n_l0;             // layer-0 slabs
+  int NS;               // slabs per step = n_l0 + 8*(L-1) + 1
+  int mode;
+  long long B;
+  // workspace layout (float offsets)
+  size_t off_coef, off_tb, off_w0p, off_wlp, off_blp, total_floats;
+};
+
+inline int plan_from_desc(const FrlDesc& d, Plan& p) {
+  p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps; p.L = d.n_hidden;
+  p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
+  p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
+  p.H = d.hidden[0];
+  p.XR = 8 * ((p.A + 7) / 8);
+  p.AR = p.XR / 2;
+  p.CK = (p.C + 1) / 2;
+  p.K0p = p.XR + 2 * p.CK;
+  p.merged = (p.K0p <= SLAB_ROWS) ? 1 : 0;
+  p.n_l0 = p.merged ? 1 : 1 + (2 * p.CK + SLAB_ROWS - 1) / SLAB_ROWS;
+  p.NS = p.n_l0 + 8 * (p.L - 1) + 1;
+  p.B = (long long)d.n_states * d.particles;
+  if (d.kind == FRL_KIND_DDPM) p.mode = (d.solver == FRL_SOLVER_DDIM) ? MODE_DDPM_DDIM : MODE_DDPM_DDPM;
+  else if (d.kind == FRL_KIND_CDDPM) p.mode = (d.solver == FRL_SOLVER_DDIM) ? MODE_CDDPM_DDIM : MODE_CDDPM_DDPM;
+  else p.mode = MODE_CNF_EULER;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };  // 256-B aligned pieces
+  p.off_coef = take((size_t)p.T * COEF_STRIDE);
+  p.off_tb = take((size_t)p.T * p.H);
+  p.off_w0p = take((size_t)(p.merged ? SLAB_ROWS : p.XR + (p.n_l0 - 1) * SLAB_ROWS) * p.H);
+  p.off_wlp = take((size_t)p.H * LAST_PAD);
+  p.off_blp = take(LAST_PAD);
+  p.total_floats = o;
+  return 0;
+}
+
+// Kernel arguments of the fused sampler (passed by value).
+struct KArgs {
+  const float* xT; const float* cond; const float* noise;
+  float* x0; float* xt_hist; float* eps_hist;
+  const float* wh[FRL_MAX_HIDDEN - 1];   // Dense_1 .. Dense_{L-1} kernels (H x H), read in place
+  const float* bh[FRL_MAX_HIDDEN - 1];
+  const float* ws_coef; const float* ws_tb; const float* ws_w0p; const float* ws_wlp; const float* ws_blp;
+  long long B;
+  int particles, A, C, T, L, mode, clip;
+  float x_min, x_max;
+  int XR, AR, CK, merged, n_l0, NS, ntiles;
+};
+
+// Arguments of the prepare kernel.
+struct PArgs {
+  FrlParams p;
+  FrlSchedule s;
+  float* ws;
+  Plan plan;
+  int kind, time_embed;
+};
+
+void set_error(const char* fmt, ...);
+
+// launchers implemented in the .hip files
+int launch_prepare(const PArgs& a, hipStream_t stream);
+int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);
+int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);
+
+}  // namespace frl

@@ -1,0 +1,173 @@
+// Stage 1 of the fused sampler: everything that is batch-invariant.
+//
+//  * per-step update coefficients, evaluated in float32 in the reference's op order
+//      DDPM            flowrl/flow/ddpm.py:199-213
+//      ContinuousDDPM  flowrl/flow/continuous_ddpm.py:165-177
+//      CNF             flowrl/flow/cnf.py:108
+//  * the time branch of DDPMBackbone / FlowBackbone (ddpm.py:83-88, cnf.py:30-35):
+//      time embedding (time_embedding.py:6-27) -> MLP[D, D] with mish after BOTH Dense layers
+//      (mlp.py:25-33, output_dim = 0) -> its slice of predictor Dense_0.  The time value is the
+//      same for every chain of a sampler call, so the slice collapses to a [T, H] bias table
+//          tb[j] = bias_0 + tfeat[j] @ kernel_0[A : A + D', :]
+//  * zero-padded, MFMA-friendly images of the two edge layers (Dense_0's x / cond rows, Dense_L).
+//
+// One workgroup; O(T * (D^2 + D*H)) work — microseconds.  Transcendentals here go through double
+// precision so that each f32 op of the reference is reproduced correctly rounded.
+#include "frl_internal.h"
+
+namespace frl {
+
+__device__ __forceinline__ float mish_exact(float x) {
+  // x * tanh(softplus(x)), functional/activation.py:17-18, correctly rounded via double
+  double xd = (double)x;
+  double sp = (xd > 30.0) ? xd : log1p(exp(xd));
+  return (float)(xd * tanh(sp));
+}
+
+__global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
+  extern __shared__ float sh[];  // 3 * T * Dmax floats
+  const Plan& pl = a.plan;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int T = pl.T, H = pl.H, A = pl.A, C = pl.C, D = pl.D, Dp = pl.Dp;
+  float* ws = a.ws;
+  float* coef = ws + pl.off_coef;
+  float* tb = ws + pl.off_tb;
+  float* w0p = ws + pl.off_w0p;
+  float* wlp = ws + pl.off_wlp;
+  float* blp = ws + pl.off_blp;
+  float* temb = sh;                 // [T][D]
+  float* h1 = sh + (size_t)T * (D > 0 ? D : 1);
+  float* h2 = h1 + (size_t)T * (D > 0 ? D : 1);
+  __shared__ float tvals[256];      // time input of loop iteration j (T <= 256 checked on host)
+
+  // ---- coefficients + time values -------------------------------------------------------------
+  for (int j = tid; j < T; j += nt) {
+    float c[COEF_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float tv;
+    if (pl.mode == MODE_CNF_EULER) {
+      tv = (float)j / (float)T;              // step2t(arange(steps)), cnf.py:80-83,139
+      c[0] = (float)T;                       // x_next = xt + vel / steps, cnf.py:108
+    } else {
+      const int t = T - j;                   // scan over arange(steps, 0, -1), ddpm.py:219
+      const float ah = a.s.alpha_hats[t], ah1 = a.s.alpha_hats[t - 1], al = a.s.alphas[t];
+      if (pl.mode == MODE_DDPM_DDPM) {
+        tv = (float)t;
+        c[0] = 1.0f / sqrtf(ah);             // x0_hat = c0 * (xt - c1 * eps)
+        c[1] = sqrtf(1.0f - ah);
+        c[2] = 1.0f / (1.0f - ah);           // xt_1 = c2 * (c3 * x0_hat + c4 * xt)
+        c[3] = sqrtf(ah1) * (1.0f - al);
+        c[4] = sqrtf(al) * (1.0f - ah1);
+        c[5] = (t > 1 ? 1.0f : 0.0f) * sqrtf(a.s.postvars[t]);   // (t>1) * std_t
+      } else if (pl.mode == MODE_DDPM_DDIM) {
+        tv = (float)t;
+        c[0] = 1.0f / sqrtf(al);             // alpha_1
+        c[1] = sqrtf(1.0f - ah);             // alpha_2
+        c[2] = sqrtf(1.0f - ah1);            // alpha_3
+      } else {
+        const float be = a.s.betas[t];
+        tv = a.s.ts[t];
+        c[0] = sqrtf(ah);                    // x0_hat = (xt - c1 * eps) / c0
+        c[1] = sqrtf(1.0f - ah);
+        if (pl.mode == MODE_CDDPM_DDPM) {
+          c[2] = sqrtf(ah1) * be / (1.0f - ah);            // mean_coef1
+          c[3] = sqrtf(al) * (1.0f - ah1) / (1.0f - ah);   // mean_coef2
+          c[5] = (t > 1 ? 1.0f : 0.0f) * sqrtf(be);
+        } else {
+          c[2] = sqrtf(ah1);
+          c[3] = sqrtf(1.0f - ah1);
+        }
+      }
+    }
+    tvals[j] = tv;
+    for (int k = 0; k < COEF_STRIDE; ++k) coef[j * COEF_STRIDE + k] = c[k];
+  }
+  __syncthreads();
+
+  const float* W0 = a.p.kernel[0];
+  const float* b0 = a.p.bias[0];
+
+  if (a.time_embed == FRL_TEMB_NONE) {
+    // raw scalar time is input column A of Dense_0 (cnf.py:38-41)
+    for (int idx = tid; idx < T * H; idx += nt) {
+      const int j = idx / H, f = idx - j * H;
+      tb[idx] = fmaf(tvals[j], W0[(size_t)A * H + f], b0[f]);
+    }
+  } else {
+    const int half = D / 2;
+    // ---- embedding ------------------------------------------------------------------------------
+    for (int idx = tid; idx < T * D; idx += nt) {
+      const int j = idx / D, d = idx - j * D;
+      const int dd = (d < half) ? d : d - half;
+      float arg;
+      if (a.time_embed == FRL_TEMB_POSITIONAL) {
+        // f = log(max_positions)/(half-1); f = exp(arange(half) * -f); f = x * f   (all f32)
+        const float lf = (float)log(10000.0) / (float)(half - 1);
+        const float fr = (float)exp((double)((float)dd * -lf));
+        arg = tvals[j] * fr;
+      } else {
+        // f = 2*pi*x @ w.T, w (D/2, 1)
+        const float two_pi_x = 6.283185307179586f * tvals[j];
+        arg = two_pi_x * a.p.time_kernel[dd];
+      }
+      temb[idx] = (d < half) ? (float)cos((double)arg) : (float)sin((double)arg);   // cos first
+    }
+    __syncthreads();
+    // ---- MLP_0/Dense_0 + mish ---------------------------------------------------------------------
+    for (int idx = tid; idx < T * D; idx += nt) {
+      const int j = idx / D, d = idx - j * D;
+      float acc = 0.0f;
+      for (int k = 0; k < D; ++k) acc = fmaf(temb[j * D + k], a.p.tmlp_kernel[0][(size_t)k * D + d], acc);
+      h1[idx] = mish_exact(acc + a.p.tmlp_bias[0][d]);
+    }
+    __syncthreads();
+    // ---- MLP_0/Dense_1 + mish ---------------------------------------------------------------------
+    for (int idx = tid; idx < T * D; idx += nt) {
+      const int j = idx / D, d = idx - j * D;
+      float acc = 0.0f;
+      for (int k = 0; k < D; ++k) acc = fmaf(h1[j * D + k], a.p.tmlp_kernel[1][(size_t)k * D + d], acc);
+      h2[idx] = mish_exact(acc + a.p.tmlp_bias[1][d]);
+    }
+    __syncthreads();
+    // ---- time slice of predictor Dense_0 -> bias table --------------------------------------------
+    for (int idx = tid; idx < T * H; idx += nt) {
+      const int j = idx / H, f = idx - j * H;
+      float acc = 0.0f;
+      for (int k = 0; k < D; ++k) acc = fmaf(h2[j * D + k], W0[(size_t)(A + k) * H + f], acc);
+      tb[idx] = acc + b0[f];
+    }
+  }
+
+  // ---- packed layer-0 image: rows [0, XR) = x rows (zero beyond A), then cond rows (zero beyond C) --
+  const int w0_rows = pl.merged ? SLAB_ROWS : pl.XR + (pl.n_l0 - 1) * SLAB_ROWS;
+  for (int idx = tid; idx < w0_rows * H; idx += nt) {
+    const int r = idx / H, f = idx - r * H;
+    float v = 0.0f;
+    if (r < pl.XR) {
+      if (r < A) v = W0[(size_t)r * H + f];
+    } else {
+      const int k = r - pl.XR;
+      if (k < C) v = W0[(size_t)(A + Dp + k) * H + f];
+    }
+    w0p[idx] = v;
+  }
+  // ---- last layer padded to LAST_PAD output columns ---------------------------------------------------
+  const int HL = pl.H;   // width of the last hidden layer
+  const float* WL = a.p.kernel[pl.L];
+  for (int idx = tid; idx < HL * LAST_PAD; idx += nt) {
+    const int k = idx / LAST_PAD, i = idx - k * LAST_PAD;
+    wlp[idx] = (i < A) ? WL[(size_t)k * A + i] : 0.0f;
+  }
+  for (int i = tid; i < LAST_PAD; i += nt) blp[i] = (i < A) ? a.p.bias[pl.L][i] : 0.0f;
+}
+
+int launch_prepare(const PArgs& a, hipStream_t stream) {
+  const int Dm = a.plan.D > 0 ? a.plan.D : 1;
+  const size_t shbytes = (size_t)3 * a.plan.T * Dm * sizeof(float);
+  if (shbytes > 60000) { set_error("prepare: T*time_dim too large (%zu B of LDS)", shbytes); return FRL_EUNSUPPORTED; }
+  hipLaunchKernelGGL(frl_prepare_kernel, dim3(1), dim3(256), shbytes, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+}  // namespace frl

@@ -1,0 +1,14 @@
+"""flowrl_hip — MI355X-native fused action sampler behind FlowRL's sampler entry points.
+
+Drop-in surface (same names, argument order and return structure as the reference):
+  flowrl_hip.flow.ddpm.DDPM.sample                        <- flowrl/flow/ddpm.py:173-221
+  flowrl_hip.flow.continuous_ddpm.ContinuousDDPM.sample   <- flowrl/flow/continuous_ddpm.py:117-222
+  flowrl_hip.flow.cnf.ContinuousNormalizingFlow.sample    <- flowrl/flow/cnf.py:113-141
+All arithmetic runs in libflowrl_hip.so (hand-written HIP for gfx950) through the C ABI in
+include/flowrl_hip.h; there is no CPU / eager fallback.
+"""
+__version__ = "0.1.0"
+
+from . import _lib  # noqa: F401
+from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, PositionalEmbedding,  # noqa: F401
+                     LearnableFourierEmbedding, init_params, tree_from_numpy, tree_to)

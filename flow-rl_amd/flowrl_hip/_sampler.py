@@ -1,0 +1,203 @@
+"""Marshal one sampler call onto the C ABI (include/flowrl_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every byte of arithmetic happens in
+libflowrl_hip.so.  There is no eager / CPU fallback — a missing library or an unsupported
+configuration raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .module import LearnableFourierEmbedding, PositionalEmbedding
+
+_ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), 0)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _f32c(t: torch.Tensor, device: torch.device, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: float32 required (got {t.dtype}); the fused path computes in f32")
+    if t.device != device:
+        raise ValueError(f"{what}: on {t.device}, expected {device}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _split_condition(xT: torch.Tensor, condition: Optional[torch.Tensor], particles: Optional[int]):
+    """Flatten leading dims; recover (n_states, particles) so obs_repeat (dql.py:145, qvpo.py:33) is
+    never materialised: a condition expanded with stride 0 over the particle axis, or an explicit
+    ``particles=N`` with an un-repeated condition, is passed as (n_states, C)."""
+    A = xT.shape[-1]
+    B = xT.numel() // A if A > 0 else 0
+    if condition is None:
+        return B, 1, None
+    Cdim = condition.shape[-1]
+    if particles is not None and particles > 1:
+        if condition.numel() // Cdim * particles != B:
+            raise ValueError("particles does not match xT / condition leading dims")
+        return B // particles, particles, condition.reshape(-1, Cdim)
+    if condition.shape[:-1] != xT.shape[:-1]:
+        raise ValueError(f"condition leading dims {tuple(condition.shape[:-1])} != xT {tuple(xT.shape[:-1])}")
+    if condition.dim() >= 3 and condition.stride(-2) == 0 and condition.shape[-2] > 1:
+        n = condition.shape[-2]
+        base = condition.select(-2, 0)
+        return B // n, n, base.reshape(-1, Cdim)
+    return B, 1, condition.reshape(-1, Cdim)
+
+
+def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, particles: int, x_dim: int,
+               cond_dim: int, clip_sampler: bool, x_min, x_max, want_history: bool) -> _lib.FrlDesc:
+    pred = network.predictor
+    if network.cond_embedding is not None:
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "cond_embedding MLP is not in the fused path yet")
+    if pred.layer_norm or (pred.dropout and pred.dropout > 0):
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "layer_norm / dropout>0 backbones are outside the fused path")
+    if len(pred.hidden_dims) < 1 or len(pred.hidden_dims) > _lib.FRL_MAX_HIDDEN:
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, f"{len(pred.hidden_dims)} hidden layers")
+    d = _lib.FrlDesc()
+    d.abi_version = _lib.FRL_ABI_VERSION
+    d.kind, d.solver, d.steps = kind, solver, steps
+    d.n_states, d.particles = n_states, particles
+    d.x_dim, d.cond_dim = x_dim, cond_dim
+    te = network.time_embedding
+    if te is None:
+        d.time_embed, d.time_dim = _lib.FRL_TEMB_NONE, 0
+    elif isinstance(te, PositionalEmbedding):
+        if te.max_positions != 10000:
+            raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "PositionalEmbedding.max_positions != 10000")
+        d.time_embed, d.time_dim = _lib.FRL_TEMB_POSITIONAL, te.output_dim
+    elif isinstance(te, LearnableFourierEmbedding):
+        d.time_embed, d.time_dim = _lib.FRL_TEMB_FOURIER, te.output_dim
+    else:
+        raise TypeError(f"unknown time embedding {type(te)}")
+    d.n_hidden = len(pred.hidden_dims)
+    for i, h in enumerate(pred.hidden_dims):
+        d.hidden[i] = int(h)
+    d.act = _lib.FRL_ACT[pred.act_name]
+    d.clip = 1 if clip_sampler else 0
+    d.x_min = float(x_min) if x_min is not None else 0.0
+    d.x_max = float(x_max) if x_max is not None else 0.0
+    d.dtype = _lib.FRL_DTYPE_F32
+    d.want_history = 1 if want_history else 0
+    return d
+
+
+def build_params(network, params: Dict, device: torch.device, keep: list) -> _lib.FrlParams:
+    """Point FrlParams at the leaves of the Flax-layout tree (no copies for contiguous f32 leaves)."""
+    fp = _lib.FrlParams()
+    te = network.time_embedding
+
+    def leaf(path):
+        node = params
+        for k in path:
+            if k not in node:
+                raise KeyError("params tree is missing " + "/".join(path))
+            node = node[k]
+        t = _f32c(node, device, "/".join(path))
+        keep.append(t)
+        return t.data_ptr()
+
+    if te is not None:
+        for i in range(2):
+            fp.tmlp_kernel[i] = leaf(("MLP_0", f"Dense_{i}", "kernel"))
+            fp.tmlp_bias[i] = leaf(("MLP_0", f"Dense_{i}", "bias"))
+        if isinstance(te, LearnableFourierEmbedding):
+            fp.time_kernel = leaf(("time_embedding", "kernel"))
+    n = len(network.predictor.hidden_dims)
+    for i in range(n + 1):
+        fp.kernel[i] = leaf((network.predictor_name, f"Dense_{i}", "kernel"))
+        fp.bias[i] = leaf((network.predictor_name, f"Dense_{i}", "bias"))
+    return fp
+
+
+def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None:
+    te = network.time_embedding
+    d_time = 1 if te is None else te.output_dim
+    dims = [x_dim + d_time + cond_dim, *network.predictor.hidden_dims, x_dim]
+    pp = params[network.predictor_name]
+    for i in range(len(dims) - 1):
+        k, b = pp[f"Dense_{i}"]["kernel"], pp[f"Dense_{i}"]["bias"]
+        if tuple(k.shape) != (dims[i], dims[i + 1]) or tuple(b.shape) != (dims[i + 1],):
+            raise ValueError(f"{network.predictor_name}/Dense_{i}: kernel {tuple(k.shape)} bias {tuple(b.shape)}, "
+                             f"expected {(dims[i], dims[i + 1])} / {(dims[i + 1],)} (input order x | time | cond)")
+    if te is not None:
+        for i in range(2):
+            k = params["MLP_0"][f"Dense_{i}"]["kernel"]
+            if tuple(k.shape) != (d_time, d_time):
+                raise ValueError(f"MLP_0/Dense_{i}/kernel {tuple(k.shape)}, expected {(d_time, d_time)}")
+        if isinstance(te, LearnableFourierEmbedding):
+            k = params["time_embedding"]["kernel"]
+            if tuple(k.shape) != (d_time // 2, 1):
+                raise ValueError(f"time_embedding/kernel {tuple(k.shape)}, expected {(d_time // 2, 1)}")
+
+
+def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
+                condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
+                clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None):
+    """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored."""
+    lib = _lib.load()
+    if not xT.is_cuda:
+        raise RuntimeError("flowrl_hip samplers run on the GPU only (xT must be a CUDA/HIP tensor); there is no CPU fallback")
+    device = xT.device
+    A = xT.shape[-1]
+    lead = tuple(xT.shape[:-1])
+    n_states, parts, cond2d = _split_condition(xT, condition, particles)
+    B = n_states * parts
+    cond_dim = 0 if cond2d is None else cond2d.shape[-1]
+    check_param_shapes(network, params, A, cond_dim)
+    keep: list = []
+    desc = build_desc(network, kind=kind, solver=solver, steps=steps, n_states=n_states, particles=parts, x_dim=A,
+                      cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history)
+    fparams = build_params(network, params, device, keep)
+
+    fs = _lib.FrlSchedule()
+    for name in ("betas", "alphas", "alpha_hats", "postvars", "ts"):
+        t = sched.get(name)
+        if t is not None:
+            t = _f32c(t, device, f"sched.{name}")
+            if t.numel() != steps + 1:
+                raise ValueError(f"sched.{name} has {t.numel()} entries, expected steps+1 = {steps + 1}")
+            keep.append(t)
+            setattr(fs, name, t.data_ptr())
+
+    x_in = _f32c(xT.reshape(B, A), device, "xT")
+    x0 = torch.empty((B, A), dtype=torch.float32, device=device)
+    bufs = _lib.FrlFwdBufs()
+    bufs.xT, bufs.x0 = x_in.data_ptr(), x0.data_ptr()
+    if cond2d is not None:
+        cond2d = _f32c(cond2d, device, "condition")
+        bufs.cond = cond2d.data_ptr()
+    if noise is not None:
+        if noise.numel() != steps * B * A:
+            raise ValueError(f"noise has {noise.numel()} elements, expected (T, ..., A) = {steps * B * A}")
+        noise = _f32c(noise.reshape(steps, B, A), device, "noise")
+        bufs.noise = noise.data_ptr()
+    xt_hist = eps_hist = None
+    if history:
+        xt_hist = torch.empty((steps, B, A), dtype=torch.float32, device=device)
+        eps_hist = torch.empty((steps, B, A), dtype=torch.float32, device=device)
+        bufs.xt_hist, bufs.eps_hist = xt_hist.data_ptr(), eps_hist.data_ptr()
+
+    _lib.check(lib.frl_validate(C.byref(desc)))
+    need = lib.frl_workspace_bytes(C.byref(desc))
+    ws = _workspace(need, device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        rc = lib.frl_sampler_fwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs),
+                                 ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc)
+    x0 = x0.reshape(*lead, A)
+    if history:
+        return x0, (xt_hist.reshape(steps, *lead, A), eps_hist.reshape(steps, *lead, A))
+    return x0, (None, None)

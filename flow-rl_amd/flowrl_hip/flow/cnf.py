@@ -1,0 +1,47 @@
+"""Flow-matching / CNF Euler sampler — host mirror of flowrl/flow/cnf.py
+(class ContinuousNormalizingFlow, :46-141)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib
+from .._sampler import run_sampler
+from ..module import FlowBackbone, init_params
+
+
+@dataclass
+class ContinuousNormalizingFlow:
+    network: FlowBackbone
+    params: Dict
+    x_dim: int = None
+    steps: int = None
+    clip_sampler: bool = None
+    x_min: float = None
+    x_max: float = None
+
+    @classmethod
+    def create(cls, network: FlowBackbone, rng, inputs, x_dim: int, steps: int, clip_sampler: bool = False,
+               x_min: Optional[float] = None, x_max: Optional[float] = None, optimizer=None,
+               clip_grad_norm: float = None, *, params: Optional[Dict] = None, device="cuda"):
+        """Mirror of ContinuousNormalizingFlow.create (cnf.py:56-78)."""
+        cond_dim = inputs[2].shape[-1] if len(inputs) > 2 and inputs[2] is not None else 0
+        if params is None:
+            params = init_params(network, x_dim, cond_dim, seed=int(rng) if rng is not None else 0, device=device)
+        return cls(network=network, params=params, x_dim=x_dim, steps=steps, clip_sampler=clip_sampler,
+                   x_min=x_min, x_max=x_max)
+
+    def replace(self, **kw):
+        return replace(self, **kw)
+
+    def sample(self, rng, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+               params: Optional[Dict] = None, *, history: bool = False, particles: Optional[int] = None):
+        """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps."""
+        p = params if (training and params is not None) else self.params
+        x1, hist = run_sampler(
+            self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xT=x0,
+            condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
+            x_max=self.x_max, history=history, particles=particles)
+        return rng, x1, hist

@@ -1,0 +1,81 @@
+"""Continuous-time VP diffusion sampler — host mirror of flowrl/flow/continuous_ddpm.py
+(class ContinuousDDPM, :47-222; solvers ddpm and ddim run fused, dpm2 / dpm++2m are not built)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from functools import partial
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from .. import _lib, schedules
+from .._sampler import run_sampler
+from ..module import DDPMBackbone, init_params
+from .ddpm import draw_noise
+
+
+@dataclass
+class ContinuousDDPM:
+    network: DDPMBackbone
+    params: Dict
+    x_dim: int = None
+    steps: int = None
+    clip_sampler: bool = None
+    x_min: float = None
+    x_max: float = None
+    solver: str = "ddpm"
+    t_schedule_n: float = None
+    t_diffusion: Tuple[float, float] = None
+    noise_schedule_func: Callable = None
+
+    @classmethod
+    def create(cls, network: DDPMBackbone, rng, inputs, x_dim: int, steps: int, noise_schedule: str,
+               noise_schedule_params: Optional[Dict] = None, clip_sampler: bool = False,
+               x_min: Optional[float] = None, x_max: Optional[float] = None, solver: str = "ddpm",
+               t_schedule_n: float = 1.0, epsilon: float = 0.001, optimizer=None, clip_grad_norm: float = None,
+               *, params: Optional[Dict] = None, device="cuda") -> "ContinuousDDPM":
+        """Mirror of ContinuousDDPM.create (continuous_ddpm.py:61-105)."""
+        kw = dict(noise_schedule_params or {})
+        if noise_schedule == "cosine":
+            t_diffusion = [epsilon, 0.9946]
+            fn = partial(schedules.cosine_noise_schedule, **kw)
+        elif noise_schedule == "linear":
+            t_diffusion = [epsilon, 1.0]
+            fn = partial(schedules.linear_noise_schedule, **kw)
+        else:
+            raise NotImplementedError(f"Unsupported noise schedule: {noise_schedule}")
+        cond_dim = inputs[2].shape[-1] if len(inputs) > 2 and inputs[2] is not None else 0
+        if params is None:
+            params = init_params(network, x_dim, cond_dim, seed=int(rng) if rng is not None else 0, device=device)
+        return cls(network=network, params=params, x_dim=x_dim, steps=steps, clip_sampler=clip_sampler, x_min=x_min,
+                   x_max=x_max, solver=solver, t_schedule_n=t_schedule_n, t_diffusion=t_diffusion, noise_schedule_func=fn)
+
+    def replace(self, **kw) -> "ContinuousDDPM":
+        return replace(self, **kw)
+
+    def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+               solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
+               params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
+               particles: Optional[int] = None):
+        """ContinuousDDPM.sample (continuous_ddpm.py:117-222)."""
+        steps = steps or self.steps
+        t_schedule_n = t_schedule_n or self.t_schedule_n
+        solver = solver or self.solver
+        if solver not in ("ddpm", "ddim"):
+            if solver in ("dpm2", "dpm++2m"):
+                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, f"solver {solver} has no fused kernel yet")
+            raise NotImplementedError(f"Unsupported solver: {solver}")
+        ts, ah, al, be = schedules.continuous_tables(steps, self.noise_schedule_func, self.t_diffusion, t_schedule_n)
+        dev = xT.device
+        to = lambda v: torch.from_numpy(v).to(dev)
+        p = params if (training and params is not None) else self.params
+        if solver == "ddpm" and noise is None:
+            noise = draw_noise(rng, (steps, *xT.shape), xT.device)
+        x0, hist = run_sampler(
+            self.network, p, kind=_lib.FRL_KIND_CDDPM,
+            solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
+            steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
+            sched={"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)},
+            clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
+            particles=particles)
+        return rng, x0, hist

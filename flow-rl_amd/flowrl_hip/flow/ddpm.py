@@ -1,0 +1,86 @@
+"""Discrete-time DDPM sampler — host mirror of flowrl/flow/ddpm.py (class DDPM, :99-221).
+
+Only what the sampling path needs is mirrored: the static fields, the noise tables of
+``DDPM.create`` (:132-162) and ``sample`` (:173-221).  ``sample`` keeps the reference's positional
+signature and return structure ``(rng, x0, (xt_hist, eps_hist))``; the arithmetic of all T steps runs
+in one fused HIP kernel.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .. import _lib, schedules
+from .._sampler import run_sampler
+from ..module import DDPMBackbone, init_params
+
+SUPPORTED_SOLVERS = ["ddim", "ddpm"]   # ddpm.py:16-18
+
+
+def draw_noise(rng, shape, device) -> torch.Tensor:
+    """Noise for the whole chain when the caller did not supply it.  ``rng`` must be a torch.Generator
+    (or None for the global one).  Bit-compatibility with jax.random's threefry key sequence
+    (ddpm.py:188,204-206) requires the caller to pass ``noise=`` drawn with those keys."""
+    gen = rng if isinstance(rng, torch.Generator) else None
+    if gen is not None and gen.device.type != torch.device(device).type:
+        return torch.randn(shape, generator=gen, dtype=torch.float32).to(device)
+    return torch.randn(shape, generator=gen, dtype=torch.float32, device=device)
+
+
+@dataclass
+class DDPM:
+    network: DDPMBackbone
+    params: Dict
+    x_dim: int = None
+    steps: int = None
+    clip_sampler: bool = None
+    x_min: float = None
+    x_max: float = None
+    betas: torch.Tensor = None
+    alphas: torch.Tensor = None
+    alpha_hats: torch.Tensor = None
+    postvars: torch.Tensor = None
+
+    @classmethod
+    def create(cls, network: DDPMBackbone, rng, inputs, x_dim: int, steps: int, noise_schedule: str,
+               noise_schedule_params: Optional[Dict] = None, approx_postvar: bool = False,
+               clip_sampler: bool = False, x_min: Optional[float] = None, x_max: Optional[float] = None,
+               optimizer=None, clip_grad_norm: float = None, *, params: Optional[Dict] = None,
+               device="cuda") -> "DDPM":
+        """Mirror of DDPM.create (ddpm.py:113-162).  ``inputs`` = sample (x, t, cond) arrays, used only
+        for their trailing dims; ``rng`` = int seed for the parameter init when ``params`` is None."""
+        cond_dim = inputs[2].shape[-1] if len(inputs) > 2 and inputs[2] is not None else 0
+        if params is None:
+            params = init_params(network, x_dim, cond_dim, seed=int(rng) if rng is not None else 0, device=device)
+        b, a, ah, pv = schedules.ddpm_tables(steps, noise_schedule, noise_schedule_params, approx_postvar)
+        dev = torch.device(device)
+        to = lambda v: torch.from_numpy(v).to(dev)
+        return cls(network=network, params=params, x_dim=x_dim, steps=steps, clip_sampler=clip_sampler,
+                   x_min=x_min, x_max=x_max, betas=to(b), alphas=to(a), alpha_hats=to(ah), postvars=to(pv))
+
+    def replace(self, **kw) -> "DDPM":
+        return replace(self, **kw)
+
+    def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+               solver: str = "ddpm", params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None,
+               history: bool = False, particles: Optional[int] = None
+               ) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+        """DDPM.sample (ddpm.py:173-221).  Extra keyword-only arguments:
+        ``noise`` (T, *xT.shape): the per-iteration N(0, I) draws (iteration j <-> t = T - j);
+        ``history``: also return (xt_hist, eps_hist) (ddpm.py:217); ``particles``: chains per condition
+        row when ``condition`` is passed un-repeated."""
+        if solver not in SUPPORTED_SOLVERS:
+            raise NotImplementedError(f"Unsupported solver {solver} for {type(self)}")
+        p = params if (training and params is not None) else self.params   # ddpm.py:191-196
+        if solver == "ddpm" and noise is None:
+            noise = draw_noise(rng, (self.steps, *xT.shape), xT.device)
+        x0, hist = run_sampler(
+            self.network, p, kind=_lib.FRL_KIND_DDPM,
+            solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
+            steps=self.steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
+            sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
+            clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
+            particles=particles)
+        return rng, x0, hist

@@ -1,0 +1,166 @@
+/*
+ * flowrl_hip.h — C ABI of libflowrl_hip.so: the MI355X (gfx950) fused action sampler.
+ *
+ * Drop-in boundary for the ONE hot path of typoverflow/flow-rl: batched reverse-diffusion /
+ * flow-ODE action sampling.  The reference has no plugin / FFI interface (it is pure JAX); the
+ * boundary is created at its three sampler entry points, whose semantics each entry below
+ * replaces (paths relative to the reference checkout):
+ *
+ *   DDPM.sample                        flowrl/flow/ddpm.py:173-221
+ *   ContinuousDDPM.sample              flowrl/flow/continuous_ddpm.py:117-222   (solvers ddpm, ddim)
+ *   ContinuousNormalizingFlow.sample   flowrl/flow/cnf.py:113-141
+ *   DDPMBackbone / FlowBackbone        flowrl/flow/ddpm.py:70-95, flowrl/flow/cnf.py:17-42
+ *   MLP (Dense -> act)*L -> Dense      flowrl/module/mlp.py:10-34, flowrl/agent/offline/fql/network.py:10-35
+ *   Positional / LearnableFourier      flowrl/module/time_embedding.py:6-27
+ *
+ * Plain C, plain pointers and sizes, no torch / JAX types.  Every pointer in FrlParams,
+ * FrlSchedule and FrlFwdBufs is DEVICE memory (float32, C-contiguous) owned by the caller; the
+ * library never allocates, frees or retains them.  All entry points only ENQUEUE work on
+ * `stream` (no host synchronisation) and return 0 on success or a negative FRL_E* code; the
+ * message is available from frl_last_error() (thread-local).  Shape validation happens before
+ * any launch.  The XLA-FFI handler (csrc/xla_ffi_shim.cc, compiled only where jaxlib's headers
+ * exist) is a thin translation onto frl_sampler_fwd; INTEGRATION.md shows the binding.
+ */
+#ifndef FLOWRL_HIP_H_
+#define FLOWRL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRL_ABI_VERSION 1
+#define FRL_MAX_HIDDEN 8 /* hidden Dense layers of the predictor MLP (mlp.py:25) */
+
+/* error codes */
+#define FRL_OK 0
+#define FRL_EINVAL (-1)       /* bad descriptor / null pointer / size mismatch          */
+#define FRL_EUNSUPPORTED (-2) /* valid reference config this build has no kernel for    */
+#define FRL_EWORKSPACE (-3)   /* workspace too small / misaligned                        */
+#define FRL_EHIP (-4)         /* a HIP runtime call failed (message has hipGetErrorString) */
+
+/* sampler kind == which reference class' sample() is reproduced */
+#define FRL_KIND_DDPM 0  /* flowrl/flow/ddpm.py:173            time input = int step t (as f32) */
+#define FRL_KIND_CDDPM 1 /* flowrl/flow/continuous_ddpm.py:117 time input = ts[i]               */
+#define FRL_KIND_CNF 2   /* flowrl/flow/cnf.py:113             time input = k / steps           */
+
+#define FRL_SOLVER_DDPM 0  /* ddpm.py:198-206 / continuous_ddpm.py:170-174 */
+#define FRL_SOLVER_DDIM 1  /* ddpm.py:207-213 / continuous_ddpm.py:176-177 */
+#define FRL_SOLVER_EULER 2 /* cnf.py:92-111 */
+
+#define FRL_TEMB_NONE 0       /* raw scalar t concatenated (FQL: cnf.py:30-41 with time_embedding=None) */
+#define FRL_TEMB_POSITIONAL 1 /* time_embedding.py:6-16  */
+#define FRL_TEMB_FOURIER 2    /* time_embedding.py:19-27 */
+
+#define FRL_ACT_MISH 0      /* functional/activation.py:17-18 */
+#define FRL_ACT_SILU 1      /* jax.nn.silu  (activation.py:13) */
+#define FRL_ACT_RELU 2      /* jax.nn.relu  (activation.py:10) */
+#define FRL_ACT_GELU_TANH 3 /* flax.linen.gelu approximate=True (fql/fql.py:199) */
+#define FRL_ACT_TANH 4      /* jax.nn.tanh  (activation.py:14) */
+#define FRL_ACT_ELU 5       /* jax.nn.elu   (activation.py:11) */
+
+#define FRL_DTYPE_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the bit-faithful path */
+#define FRL_DTYPE_BF16 1 /* reserved: bf16 MFMA, f32 accumulate / chain state */
+
+/* Static description of one sampler call — the analogue of the reference's jit static_argnames
+ * plus the pytree_node=False fields of DDPM / ContinuousDDPM / ContinuousNormalizingFlow
+ * (ddpm.py:103-107, continuous_ddpm.py:51-59, cnf.py:50-54). */
+typedef struct FrlDesc {
+  int32_t abi_version; /* FRL_ABI_VERSION */
+  int32_t kind;        /* FRL_KIND_*   */
+  int32_t solver;      /* FRL_SOLVER_* */
+  int32_t steps;       /* T */
+  int64_t n_states;    /* number of distinct condition rows */
+  int32_t particles;   /* chains per state; B = n_states * particles chains (dql.py:145 obs_repeat is
+                          NOT materialised: the kernel broadcasts each condition row) */
+  int32_t x_dim;       /* A: action dim */
+  int32_t cond_dim;    /* C: condition features reaching the predictor; 0 = no condition */
+  int32_t time_embed;  /* FRL_TEMB_* */
+  int32_t time_dim;    /* D (output_dim of the embedding); ignored for FRL_TEMB_NONE */
+  int32_t n_hidden;    /* L: number of hidden Dense layers of the predictor */
+  int32_t hidden[FRL_MAX_HIDDEN]; /* their widths */
+  int32_t act;         /* FRL_ACT_* of the predictor (the time MLP is always mish, ddpm.py:85-88) */
+  int32_t clip;        /* clip_sampler */
+  float x_min, x_max;
+  int32_t dtype;        /* FRL_DTYPE_* */
+  int32_t want_history; /* 1: write xt_hist / eps_hist (ddpm.py:217) */
+} FrlDesc;
+
+/* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a
+ * DDPMBackbone / FlowBackbone; nn.Dense kernels are (in, out) row-major and are read IN PLACE. */
+typedef struct FrlParams {
+  const float* time_kernel;    /* params/time_embedding/kernel (D/2, 1); FRL_TEMB_FOURIER only   */
+  const float* tmlp_kernel[2]; /* params/MLP_0/Dense_{0,1}/kernel (D, D); NULL for FRL_TEMB_NONE  */
+  const float* tmlp_bias[2];   /* params/MLP_0/Dense_{0,1}/bias   (D,)                            */
+  const float* kernel[FRL_MAX_HIDDEN + 1]; /* params/{noise,vel}_predictor/Dense_i/kernel; i = 0..L     */
+  const float* bias[FRL_MAX_HIDDEN + 1];   /* .../Dense_i/bias. Dense_0 kernel is (A + D' + C, H0) with
+                                              row order x | time | cond (ddpm.py:92), D' = D or 1      */
+} FrlParams;
+
+/* Noise-schedule tables, each (T+1,) float32 on the device.
+ * DDPM:  the model's own pytree leaves betas/alphas/alpha_hats/postvars (ddpm.py:108-111), verbatim.
+ * CDDPM: the per-call tables of continuous_ddpm.py:134-138 (postvars unused, ts required).
+ * CNF:   all NULL. */
+typedef struct FrlSchedule {
+  const float* betas;
+  const float* alphas;
+  const float* alpha_hats;
+  const float* postvars;
+  const float* ts;
+} FrlSchedule;
+
+typedef struct FrlFwdBufs {
+  const float* xT;    /* (B, A)  start of the chain (x0 for CNF)                          */
+  const float* cond;  /* (n_states, C) un-repeated condition rows, NULL iff cond_dim == 0  */
+  const float* noise; /* (T, B, A): noise[j] = the N(0,I) draw of loop iteration j (ddpm.py:206,
+                         continuous_ddpm.py:174), drawn by the caller with the reference's key
+                         sequence.  NULL for solvers without noise (ddim, euler)              */
+  float* x0;          /* (B, A)  result                                                    */
+  float* xt_hist;     /* (T, B, A) or NULL: input of iteration j  (history[0], ddpm.py:217)  */
+  float* eps_hist;    /* (T, B, A) or NULL: net output of iteration j (history[1])           */
+} FrlFwdBufs;
+
+/* FRL_OK if this build has a kernel for `desc`, else FRL_EINVAL / FRL_EUNSUPPORTED (message set). */
+int frl_validate(const FrlDesc* desc);
+
+/* Bytes of device scratch a call with this descriptor needs (tables, hoisted time branch,
+ * packed edge-layer weights).  256-byte aligned pointer required.  0 on invalid descriptor. */
+size_t frl_workspace_bytes(const FrlDesc* desc);
+
+/* Stage 1 (tiny kernel): per-step coefficients in the reference's op order, the batch-invariant
+ * time branch (embedding -> 2-layer mish MLP -> layer-0 time slice => a [T, H0] bias table),
+ * zero-padded copies of the first/last layer weights.  Must be re-run whenever params change. */
+int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                        void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Stage 2: the persistent fused T-step kernel.  Needs a workspace filled by frl_sampler_prepare
+ * for the same desc/params on the same stream (or an earlier, completed one). */
+int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
+                    const void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* prepare + run: the whole of DDPM.sample / ContinuousDDPM.sample / CNF.sample minus RNG. */
+int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                    const FrlFwdBufs* bufs, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Algorithmic FLOPs of one call, SURVEY.md section 8(d): 2*B*T*(K0*H + sum H_l*H_{l+1} + H*A) with
+ * the reference's full K0 = A + D' + C; `executed` (may be NULL) receives the MFMA FLOPs the kernel
+ * really issues (time slice hoisted, edge layers zero-padded). */
+double frl_algorithmic_flops(const FrlDesc* desc, double* executed);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* frl_last_error(void);
+
+/* ABI version this library was built with. */
+int frl_abi_version(void);
+
+/* Hardware self-test of the MFMA operand / accumulator lane maps the kernel relies on:
+ * D(32x32) = A(32xK) * B(Kx32) with v_mfma_f32_32x32x2_f32, row-major f32 device buffers,
+ * K even.  Used by tests/ only. */
+int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWRL_HIP_H_ */

@@ -1,0 +1,428 @@
+"""CPU oracle for the FlowRL action-sampling hot path (numpy restatement).
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it;
+the product path (``flow-rl_amd/``) never does.
+
+PARITY UNPINNED: the reference (typoverflow/flow-rl 0.2.0) ships no tests, golden
+vectors or fixtures for this path, and its arithmetic lives in third-party
+packages that are absent from this container and from /root/reference
+(jax==0.5.3, flax==0.10.5; ``import jax`` -> ModuleNotFoundError, an ordinary
+missing-module error).  This file restates the reference *text* line by line;
+what pins it instead is (1) float64 vs float32 agreement, (2) an independent
+torch-CPU restatement of the network in tests/test_oracle.py, (3) closed-form
+known-answer tests and the hand-computed table values of SURVEY.md appendix A.6.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  All arithmetic is done in ``dtype`` (float32 mirrors the
+reference's JAX default; float64 is the ground truth used for tolerances).
+
+Third-party semantics restated from their published definitions:
+  * flax.linen.Dense:  y = x @ kernel + bias, kernel stored (in, out) row-major
+  * flax.linen.softplus = logaddexp(x, 0); flax.linen.gelu(approximate=True)
+    = 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  * jax.nn.silu = x sigmoid(x); jax.nn.elu = x>0 ? x : expm1(x)
+  * flax submodule auto-naming inside @nn.compact: attribute modules keep the
+    attribute name (noise_predictor / vel_predictor / time_embedding /
+    cond_embedding), the inline time MLP is ``MLP_0``, Dense layers ``Dense_i``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------- #
+# activations — flowrl/functional/activation.py:8-18 (+ flax gelu for FQL,
+# flowrl/agent/offline/fql/fql.py:199)
+# --------------------------------------------------------------------------- #
+
+
+def softplus(x):
+    # flax.linen.softplus == jnp.logaddexp(x, 0)
+    return np.logaddexp(x, np.zeros((), dtype=x.dtype))
+
+
+def mish(x):
+    # activation.py:17-18  x * tanh(softplus(x))
+    return x * np.tanh(softplus(x))
+
+
+def silu(x):
+    one = np.ones((), dtype=x.dtype)
+    return x / (one + np.exp(-x))
+
+
+def relu(x):
+    return np.maximum(x, np.zeros((), dtype=x.dtype))
+
+
+def elu(x):
+    return np.where(x > 0, x, np.expm1(np.minimum(x, np.zeros((), dtype=x.dtype))))
+
+
+def gelu_tanh(x):
+    dt = x.dtype
+    c = np.asarray(math.sqrt(2.0 / math.pi), dtype=dt)
+    k = np.asarray(0.044715, dtype=dt)
+    half = np.asarray(0.5, dtype=dt)
+    one = np.ones((), dtype=dt)
+    return half * x * (one + np.tanh(c * (x + k * (x * x * x))))
+
+
+ACTIVATIONS = {
+    "mish": mish,
+    "silu": silu,
+    "relu": relu,
+    "elu": elu,
+    "tanh": np.tanh,
+    "gelu_tanh": gelu_tanh,
+}
+
+
+def get_activation(name: str):
+    # activation.py:8-15
+    return ACTIVATIONS[name]
+
+
+# --------------------------------------------------------------------------- #
+# noise schedules — flowrl/flow/ddpm.py:23-42 and :132-150
+# --------------------------------------------------------------------------- #
+
+
+def linear_beta_schedule(T: int, beta_min=1e-4, beta_max=2e-2, dtype=np.float32):
+    # ddpm.py:23-24
+    return np.linspace(beta_min, beta_max, T, dtype=dtype)
+
+
+def cosine_beta_schedule(T: int, s=0.008, dtype=np.float32):
+    # ddpm.py:27-33
+    steps = T + 1
+    t = np.linspace(0, T, steps, dtype=dtype) / np.asarray(T, dtype=dtype)
+    sd = np.asarray(s, dtype=dtype)
+    ac = np.cos((t + sd) / (1 + sd) * np.asarray(np.pi, dtype=dtype) * np.asarray(0.5, dtype=dtype)) ** 2
+    ac = ac / ac[0]
+    betas = 1 - (ac[1:] / ac[:-1])
+    return np.clip(betas, 0, 0.999).astype(dtype)
+
+
+def vp_beta_schedule(T: int, dtype=np.float32):
+    # ddpm.py:36-42
+    t = np.arange(1, T + 1)
+    b_max, b_min = 10.0, 0.1
+    expo = (-b_min / T - 0.5 * (b_max - b_min) * (2 * t - 1).astype(dtype) / np.asarray(T ** 2, dtype=dtype)).astype(dtype)
+    alpha = np.exp(expo)
+    return (1 - alpha).astype(dtype)
+
+
+def ddpm_tables(steps: int, noise_schedule: str, approx_postvar: bool = False,
+                noise_schedule_params: Optional[dict] = None, dtype=np.float32):
+    """betas/alphas/alpha_hats/postvars, each (T+1,) — ddpm.py:132-150."""
+    kw = dict(noise_schedule_params or {})
+    if noise_schedule == "linear":
+        betas = linear_beta_schedule(steps, dtype=dtype, **kw)
+    elif noise_schedule == "cosine":
+        betas = cosine_beta_schedule(steps, dtype=dtype, **kw)
+    elif noise_schedule == "vp":
+        betas = vp_beta_schedule(steps, dtype=dtype)
+    else:
+        raise NotImplementedError(f"Unsupported noise schedule: {noise_schedule}")
+    betas = np.concatenate([np.zeros((1,), dtype=dtype), betas.astype(dtype)])
+    alphas = (1 - betas).astype(dtype)
+    alpha_hats = np.cumprod(alphas, dtype=dtype)
+    if approx_postvar:
+        postvars = betas.copy()
+    else:
+        pv = betas[1:] * (1 - alpha_hats[:-1]) / (1 - alpha_hats[1:])
+        postvars = np.concatenate([np.zeros((1,), dtype=dtype), pv.astype(dtype)])
+    return betas, alphas, alpha_hats, postvars
+
+
+# continuous-time schedules — flowrl/flow/continuous_ddpm.py:19-40
+
+
+def linear_noise_schedule(t, beta0=0.1, beta1=20.0):
+    # continuous_ddpm.py:19-24
+    dt = t.dtype
+    log_alpha = -np.asarray((beta1 - beta0) / 4.0, dtype=dt) * (t ** 2) - np.asarray(beta0 / 2.0, dtype=dt) * t
+    alpha = np.exp(log_alpha)
+    sigma = np.sqrt(1 - alpha ** 2)
+    return alpha, sigma
+
+
+def cosine_noise_schedule(t, s=0.008):
+    # continuous_ddpm.py:26-31
+    dt = t.dtype
+    half_pi = np.asarray(np.pi / 2.0, dtype=dt)
+    sd = np.asarray(s, dtype=dt)
+    num = np.cos(half_pi * (np.clip(t, 0.0, 0.9946).astype(dt) + sd) / (1 + sd))
+    den = np.cos(half_pi * sd / (1 + sd))
+    alpha = (num / den).astype(dt)
+    sigma = np.sqrt(1 - alpha ** 2)
+    return alpha, sigma
+
+
+def quad_t_schedule(T: int, n=1.0, tmin=1e-3, tmax=1.0, dtype=np.float32):
+    # continuous_ddpm.py:35-40
+    lin = np.linspace(0, 1, T + 1, dtype=dtype)
+    return (np.asarray(tmax - tmin, dtype=dtype) * (lin ** np.asarray(n, dtype=dtype)) + np.asarray(tmin, dtype=dtype)).astype(dtype)
+
+
+def continuous_tables(steps: int, noise_schedule: str, t_schedule_n=1.0, epsilon=1e-3,
+                      noise_schedule_params: Optional[dict] = None, dtype=np.float32):
+    """ts / alpha_hats / alphas / betas built per call — continuous_ddpm.py:84-87,134-138."""
+    kw = dict(noise_schedule_params or {})
+    if noise_schedule == "cosine":
+        tmin, tmax = epsilon, 0.9946
+        fn = cosine_noise_schedule
+    elif noise_schedule == "linear":
+        tmin, tmax = epsilon, 1.0
+        fn = linear_noise_schedule
+    else:
+        raise NotImplementedError(f"Unsupported noise schedule: {noise_schedule}")
+    ts = quad_t_schedule(steps, n=t_schedule_n, tmin=tmin, tmax=tmax, dtype=dtype)
+    alpha_hats = (fn(ts, **kw)[0] ** 2).astype(dtype)
+    alphas = np.concatenate([np.ones((1,), dtype=dtype), alpha_hats[1:] / alpha_hats[:-1]]).astype(dtype)
+    betas = (1 - alphas).astype(dtype)
+    return ts, alpha_hats, alphas, betas
+
+
+# --------------------------------------------------------------------------- #
+# time embeddings — flowrl/module/time_embedding.py:6-27
+# --------------------------------------------------------------------------- #
+
+
+def positional_embedding(x, output_dim: int, max_positions: int = 10000):
+    # time_embedding.py:11-16; x has shape (..., 1)
+    dt = x.dtype
+    half = output_dim // 2
+    f = np.asarray(np.log(np.asarray(max_positions, dtype=dt)) / (half - 1), dtype=dt)
+    f = np.exp(np.arange(half).astype(dt) * -f).astype(dt)
+    f = x * f
+    return np.concatenate([np.cos(f), np.sin(f)], axis=-1).astype(dt)
+
+
+def learnable_fourier_embedding(x, kernel):
+    # time_embedding.py:23-27; kernel (D/2, in_dim)
+    dt = x.dtype
+    f = np.asarray(2 * np.pi, dtype=dt) * x @ kernel.T.astype(dt)
+    return np.concatenate([np.cos(f), np.sin(f)], axis=-1).astype(dt)
+
+
+# --------------------------------------------------------------------------- #
+# networks — flowrl/module/mlp.py:10-34, flowrl/agent/offline/fql/network.py:10-35,
+# flowrl/flow/ddpm.py:70-95, flowrl/flow/cnf.py:17-42
+# --------------------------------------------------------------------------- #
+
+
+def dense(p, x):
+    return x @ p["kernel"] + p["bias"]
+
+
+def mlp_apply(p: Dict, x, n_hidden: int, activation, has_output: bool):
+    """mlp.py:25-33 with layer_norm=False, dropout off (all shipped sampler configs)."""
+    for i in range(n_hidden):
+        x = activation(dense(p[f"Dense_{i}"], x))
+    if has_output:
+        x = dense(p[f"Dense_{n_hidden}"], x)
+    return x
+
+
+@dataclass
+class BackboneSpec:
+    """Static description of a DDPMBackbone / FlowBackbone instance."""
+    hidden_dims: Sequence[int]
+    x_dim: int
+    activation: str = "mish"
+    time_embedding: Optional[str] = "positional"   # "positional" | "learnable_fourier" | None (raw t)
+    time_dim: int = 64
+    cond_hidden: Optional[Sequence[int]] = None     # cond_embedding MLP hidden dims (dacer.py:263-266) or None
+    predictor_name: str = "noise_predictor"         # "vel_predictor" for FlowBackbone
+
+
+def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
+    """DDPMBackbone.__call__ (ddpm.py:83-95) == FlowBackbone.__call__ (cnf.py:30-42)."""
+    act = get_activation(spec.activation)
+    if spec.time_embedding is not None:
+        if spec.time_embedding == "positional":
+            time = positional_embedding(time, spec.time_dim)
+        else:
+            time = learnable_fourier_embedding(time, params["time_embedding"]["kernel"])
+        # inline MLP(hidden_dims=[D, D], activation=mish), no output layer
+        time = mlp_apply(params["MLP_0"], time, 2, mish, has_output=False)
+    if spec.cond_hidden is not None:
+        condition = mlp_apply(params["cond_embedding"], condition, len(spec.cond_hidden), act, has_output=False)
+    if condition is not None:
+        inputs = np.concatenate([x, time, condition], axis=-1)
+    else:
+        inputs = np.concatenate([x, time], axis=-1)
+    return mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, has_output=True)
+
+
+# --------------------------------------------------------------------------- #
+# samplers
+# --------------------------------------------------------------------------- #
+
+
+def _clip(x, lo, hi):
+    return np.clip(x, np.asarray(lo, dtype=x.dtype), np.asarray(hi, dtype=x.dtype))
+
+
+def ddpm_sample(spec: BackboneSpec, params: Dict, tables, xT, condition, noise, *, steps: int,
+                solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None):
+    """DDPM.sample — ddpm.py:173-221.  ``noise[j]`` is the N(0,I) draw of loop iteration j
+    (t = T - j); it is consumed at every iteration (times 0 at t == 1), exactly like
+    ``jax.random.normal(key_, xt.shape)`` at ddpm.py:206.  Returns (x0, (xt_hist, eps_hist))."""
+    dt = xT.dtype
+    betas, alphas, alpha_hats, postvars = [np.asarray(a, dtype=dt) for a in tables]
+    xt = xT
+    xt_hist, eps_hist = [], []
+    one = np.ones((), dtype=dt)
+    for j, t in enumerate(range(steps, 0, -1)):
+        input_t = np.full((*xT.shape[:-1], 1), t, dtype=np.int32).astype(dt)   # t_proto * t, promoted to float
+        eps = backbone_apply(spec, params, xt, input_t, condition)
+        if solver == "ddpm":
+            x0_hat = one / np.sqrt(alpha_hats[t]) * (xt - np.sqrt(one - alpha_hats[t]) * eps)
+            if clip_sampler:
+                x0_hat = _clip(x0_hat, x_min, x_max)
+            xt_1 = one / (one - alpha_hats[t]) * (np.sqrt(alpha_hats[t - 1]) * (one - alphas[t]) * x0_hat
+                                                  + np.sqrt(alphas[t]) * (one - alpha_hats[t - 1]) * xt)
+            std_t = np.sqrt(postvars[t])
+            xt_1 = xt_1 + np.asarray(float(t > 1), dtype=dt) * std_t * noise[j]
+        elif solver == "ddim":
+            a1 = one / np.sqrt(alphas[t])
+            a2 = np.sqrt(one - alpha_hats[t])
+            a3 = np.sqrt(one - alpha_hats[t - 1])
+            xt_1 = a1 * (xt - a2 * eps) + a3 * eps
+            if clip_sampler:
+                xt_1 = _clip(xt_1, x_min, x_max)
+        else:
+            raise NotImplementedError(f"Unsupported solver {solver}")
+        xt_hist.append(xt)
+        eps_hist.append(eps)
+        xt = xt_1.astype(dt)
+    return xt, (np.stack(xt_hist), np.stack(eps_hist))
+
+
+def continuous_ddpm_sample(spec: BackboneSpec, params: Dict, tables, xT, condition, noise, *, steps: int,
+                           solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None):
+    """ContinuousDDPM.sample — continuous_ddpm.py:117-222 (solvers ddpm / ddim).
+    ``tables`` = (ts, alpha_hats, alphas, betas) from :func:`continuous_tables`."""
+    dt = xT.dtype
+    ts, alpha_hats, alphas, betas = [np.asarray(a, dtype=dt) for a in tables]
+    xt = xT
+    xt_hist, eps_hist = [], []
+    one = np.ones((), dtype=dt)
+    for j, i in enumerate(range(steps, 0, -1)):
+        input_t = np.ones((*xT.shape[:-1], 1), dtype=dt) * ts[i]
+        eps = backbone_apply(spec, params, xt, input_t, condition)
+        x0_hat = (xt - np.sqrt(one - alpha_hats[i]) * eps) / np.sqrt(alpha_hats[i])
+        if clip_sampler:
+            x0_hat = _clip(x0_hat, x_min, x_max)
+        if solver == "ddpm":
+            c1 = np.sqrt(alpha_hats[i - 1]) * betas[i] / (one - alpha_hats[i])
+            c2 = np.sqrt(alphas[i]) * (one - alpha_hats[i - 1]) / (one - alpha_hats[i])
+            xt_1 = c1 * x0_hat + c2 * xt
+            xt_1 = xt_1 + np.asarray(float(i > 1), dtype=dt) * np.sqrt(betas[i]) * noise[j]
+        elif solver == "ddim":
+            xt_1 = np.sqrt(alpha_hats[i - 1]) * x0_hat + np.sqrt(one - alpha_hats[i - 1]) * eps
+        else:
+            raise NotImplementedError(f"Unsupported solver: {solver}")
+        xt_hist.append(xt)
+        eps_hist.append(eps)
+        xt = xt_1.astype(dt)
+    return xt, (np.stack(xt_hist), np.stack(eps_hist))
+
+
+def cnf_sample(spec: BackboneSpec, params: Dict, x0, condition, *, steps: int,
+               clip_sampler: bool = False, x_min=None, x_max=None):
+    """ContinuousNormalizingFlow.sample / _ode_step — cnf.py:92-141.  Euler, t = k / steps."""
+    dt = x0.dtype
+    xt = x0
+    xt_hist, vel_hist = [], []
+    tgrid = (np.arange(steps).astype(dt) / np.asarray(steps, dtype=dt)).astype(dt)   # step2t, cnf.py:80-83
+    for k in range(steps):
+        input_t = np.ones((*x0.shape[:-1], 1), dtype=np.int32).astype(dt) * tgrid[k]
+        vel = backbone_apply(spec, params, xt, input_t, condition)
+        x_next = xt + vel / np.asarray(steps, dtype=dt)                                # cnf.py:108
+        if clip_sampler:
+            x_next = _clip(x_next, x_min, x_max)
+        xt_hist.append(xt)
+        vel_hist.append(vel)
+        xt = x_next.astype(dt)
+    return xt, (np.stack(xt_hist), np.stack(vel_hist))
+
+
+# --------------------------------------------------------------------------- #
+# synthetic parameters (SURVEY.md section 8d "Synthetic values & seeds")
+# --------------------------------------------------------------------------- #
+
+
+def _orthogonal(rng, n_in, n_out, gain):
+    # flowrl/module/initialization.py:9-12 -> nn.initializers.orthogonal(sqrt(2))
+    a = rng.standard_normal((max(n_in, n_out), min(n_in, n_out)))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    if n_in < n_out:
+        q = q.T
+    return (gain * q[:n_in, :n_out])
+
+
+def _dense_params(rng, n_in, n_out, dtype, bias_std=0.1):
+    return {
+        "kernel": _orthogonal(rng, n_in, n_out, math.sqrt(2.0)).astype(dtype),
+        "bias": (bias_std * rng.standard_normal((n_out,))).astype(dtype),   # non-zero on purpose: zero biases hide bias bugs
+    }
+
+
+def make_params(spec: BackboneSpec, cond_dim: int, seed: int, dtype=np.float32, cond_in_dim: Optional[int] = None) -> Dict:
+    """Random parameter tree in the Flax layout of DDPMBackbone / FlowBackbone (ddpm.py:70-95).
+    ``cond_dim`` is the feature width that reaches the predictor; ``cond_in_dim`` the raw obs width
+    when a cond_embedding MLP is present."""
+    rng = np.random.default_rng(seed)
+    p: Dict = {}
+    d_time = spec.time_dim if spec.time_embedding is not None else 1
+    if spec.time_embedding is not None:
+        p["MLP_0"] = {
+            "Dense_0": _dense_params(rng, spec.time_dim, spec.time_dim, dtype),
+            "Dense_1": _dense_params(rng, spec.time_dim, spec.time_dim, dtype),
+        }
+        if spec.time_embedding == "learnable_fourier":
+            p["time_embedding"] = {"kernel": (0.2 * rng.standard_normal((spec.time_dim // 2, 1))).astype(dtype)}
+    if spec.cond_hidden is not None:
+        dims = [cond_in_dim] + list(spec.cond_hidden)
+        p["cond_embedding"] = {f"Dense_{i}": _dense_params(rng, dims[i], dims[i + 1], dtype) for i in range(len(spec.cond_hidden))}
+        cond_dim = spec.cond_hidden[-1]
+    dims = [spec.x_dim + d_time + cond_dim] + list(spec.hidden_dims) + [spec.x_dim]
+    p[spec.predictor_name] = {f"Dense_{i}": _dense_params(rng, dims[i], dims[i + 1], dtype) for i in range(len(dims) - 1)}
+    return p
+
+
+def cast_tree(tree, dtype):
+    if isinstance(tree, dict):
+        return {k: cast_tree(v, dtype) for k, v in tree.items()}
+    return np.asarray(tree, dtype=dtype)
+
+
+def flatten_tree(tree, prefix=""):
+    out = {}
+    for k, v in tree.items():
+        key = f"{prefix}/{k}" if prefix else k
+        if isinstance(v, dict):
+            out.update(flatten_tree(v, key))
+        else:
+            out[key] = v
+    return out
+
+
+def unflatten_tree(flat):
+    out: Dict = {}
+    for key, v in flat.items():
+        node = out
+        parts = key.split("/")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = v
+    return out

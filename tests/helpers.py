@@ -1,0 +1,124 @@
+"""Shared test helpers: one configuration -> oracle inputs (numpy) and product inputs (torch)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+import flowrl_oracle as orc
+
+
+@dataclass
+class Case:
+    name: str
+    kind: str                      # "ddpm" | "cddpm" | "cnf"
+    A: int
+    S: int                         # cond dim (0 = none)
+    T: int
+    B: int
+    hidden: tuple = (256, 256, 256)
+    act: str = "mish"
+    temb: Optional[str] = "positional"
+    schedule: str = "vp"
+    solver: str = "ddpm"
+    clip: bool = True
+    x_min: float = -1.0
+    x_max: float = 1.0
+    approx_postvar: bool = False
+    particles: int = 1
+    seed: int = 0
+
+    @property
+    def spec(self):
+        return orc.BackboneSpec(hidden_dims=list(self.hidden), x_dim=self.A, activation=self.act,
+                                time_embedding=self.temb, time_dim=64,
+                                predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor")
+
+
+def make_inputs(c: Case):
+    """numpy float32 inputs + params (Flax layout) for a case; condition is un-repeated (n_states, S)."""
+    rng = np.random.default_rng(1000 + c.seed)
+    params = orc.make_params(c.spec, c.S, seed=c.seed)
+    n_states = c.B // c.particles
+    assert n_states * c.particles == c.B
+    xT = rng.standard_normal((c.B, c.A)).astype(np.float32)
+    cond = rng.standard_normal((n_states, c.S)).astype(np.float32) if c.S > 0 else None
+    noise = rng.standard_normal((c.T, c.B, c.A)).astype(np.float32)
+    return params, xT, cond, noise
+
+
+def oracle_run(c: Case, params, xT, cond, noise, dtype=np.float64):
+    """Run the oracle in `dtype`; returns (x0, xt_hist, eps_hist)."""
+    p = orc.cast_tree(params, dtype)
+    x = xT.astype(dtype)
+    cd = None if cond is None else np.repeat(cond.astype(dtype), c.particles, axis=0)
+    nz = noise.astype(dtype)
+    kw = dict(steps=c.T, clip_sampler=c.clip, x_min=c.x_min, x_max=c.x_max)
+    if c.kind == "ddpm":
+        tables = orc.ddpm_tables(c.T, c.schedule, approx_postvar=c.approx_postvar, dtype=np.float32)
+        x0, (xh, eh) = orc.ddpm_sample(c.spec, p, [t.astype(dtype) for t in tables], x, cd, nz, solver=c.solver, **kw)
+    elif c.kind == "cddpm":
+        tables = orc.continuous_tables(c.T, c.schedule, dtype=np.float32)
+        x0, (xh, eh) = orc.continuous_ddpm_sample(c.spec, p, [t.astype(dtype) for t in tables], x, cd, nz, solver=c.solver, **kw)
+    else:
+        x0, (xh, eh) = orc.cnf_sample(c.spec, p, x, cd, **kw)
+    return x0, xh, eh
+
+
+def product_model(c: Case, params, device="cuda"):
+    """The flowrl_hip model object for a case (torch tensors on `device`)."""
+    import flowrl_hip as fh
+    from flowrl_hip.flow import DDPM, ContinuousDDPM, ContinuousNormalizingFlow
+    te = None
+    if c.temb == "positional":
+        te = fh.PositionalEmbedding(output_dim=64)
+    elif c.temb == "learnable_fourier":
+        te = fh.LearnableFourierEmbedding(output_dim=64)
+    mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act)
+    tparams = fh.tree_from_numpy(params, device)
+    inputs = (np.ones((1, c.A)), np.zeros((1, 1)), np.ones((1, c.S)) if c.S > 0 else None)
+    if c.kind == "ddpm":
+        net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te)
+        return DDPM.create(net, 0, inputs, x_dim=c.A, steps=c.T, noise_schedule=c.schedule,
+                           approx_postvar=c.approx_postvar, clip_sampler=c.clip, x_min=c.x_min, x_max=c.x_max,
+                           params=tparams, device=device)
+    if c.kind == "cddpm":
+        net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te)
+        return ContinuousDDPM.create(net, 0, inputs, x_dim=c.A, steps=c.T, noise_schedule=c.schedule,
+                                     clip_sampler=c.clip, x_min=c.x_min, x_max=c.x_max, solver=c.solver,
+                                     params=tparams, device=device)
+    net = fh.FlowBackbone(vel_predictor=mlp, time_embedding=te)
+    return ContinuousNormalizingFlow.create(net, 0, inputs, x_dim=c.A, steps=c.T, clip_sampler=c.clip,
+                                            x_min=c.x_min, x_max=c.x_max, params=tparams, device=device)
+
+
+def product_run(c: Case, model, xT, cond, noise, device="cuda", history=True):
+    import torch
+    x = torch.from_numpy(xT).to(device)
+    cd = None if cond is None else torch.from_numpy(cond).to(device)
+    nz = torch.from_numpy(noise).to(device)
+    kw = dict(history=history, particles=c.particles if c.particles > 1 else None)
+    if c.kind == "ddpm":
+        _, x0, (xh, eh) = model.sample(None, x, cd, False, c.solver, noise=nz, **kw)
+    elif c.kind == "cddpm":
+        _, x0, (xh, eh) = model.sample(None, x, cd, False, c.solver, noise=nz, **kw)
+    else:
+        _, x0, (xh, eh) = model.sample(None, x, cd, **kw)
+    torch.cuda.synchronize()
+    f = lambda t: None if t is None else t.cpu().numpy()
+    return f(x0), f(xh), f(eh)
+
+
+def rel_err(got, ref):
+    """max |got - ref| / max(|ref|, 1): the parity metric of SURVEY.md section 7 (hard parts)."""
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - ref) / np.maximum(np.abs(ref), 1.0))) if ref.size else 0.0
+
+
+def rms_err(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.size == 0:
+        return 0.0
+    d = (np.asarray(got, dtype=np.float64) - ref) / np.maximum(np.abs(ref), 1.0)
+    return float(np.sqrt(np.mean(d * d)))
