@@ -1,0 +1,215 @@
+"""bench.py — headline benchmark of the fused action sampler (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+
+One "step" = one full sampler call (frl_sampler_prepare + the fused T-step kernel) over one batch of
+synthetic chains that is already resident in HBM.  Default workload = BASELINE.json configs[1]
+("cfg2": DQL/DAC hopper shape, obs 11, act 3, 256x3 mish MLP, vp schedule, T=5, clip +-1,
+B = 262,144 chains per GPU).  Multi-GPU: one process per GPU (torch.distributed / RCCL), chains
+sharded by state index (weak scaling: every rank owns B chains), the only collective is the final
+all-gather of x0 (BASELINE.json north_star), inside the timed region.
+
+Prints ONE JSON line on rank 0.  value = chain-steps/s = (ranks * B * T) / (time per step).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT / "flow-rl_amd")]
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32)
+
+WORKLOADS = {
+    # name: dict(kind, A, S, T, B, hidden, act, schedule, clip, x_min, x_max)
+    "cfg1": dict(desc="toy2d DDPM (obs 1, act 2, 256x3 mish, linear, T=20, B=4096)",
+                 A=2, S=1, T=20, B=4096, hidden=[256, 256, 256], act="mish", schedule="linear", clip=False,
+                 x_min=-4.0, x_max=4.0),
+    "cfg2": dict(desc="DQL/DAC DDPM hopper (obs 11, act 3, 256x3 mish, vp, T=5, clip +-1, B=262144/GPU)",
+                 A=3, S=11, T=5, B=262144, hidden=[256, 256, 256], act="mish", schedule="vp", clip=True,
+                 x_min=-1.0, x_max=1.0),
+}
+
+
+def build_model(w, device, seed=0):
+    import flowrl_hip as fh
+    from flowrl_hip.flow import DDPM
+    net = fh.DDPMBackbone(noise_predictor=fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"]),
+                          time_embedding=fh.PositionalEmbedding(output_dim=64))
+    params = fh.init_params(net, w["A"], w["S"], seed=seed, bias_std=0.1, device=device)
+    inputs = (np.ones((1, w["A"])), np.zeros((1, 1)), np.ones((1, w["S"])))
+    return DDPM.create(net, 0, inputs, x_dim=w["A"], steps=w["T"], noise_schedule=w["schedule"],
+                       clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], params=params, device=device)
+
+
+def kernel_only_ms(model, w, xT, cond, noise, iters):
+    """Average duration of the dominant kernel (the fused T-step sampler) alone: prepare once, then
+    `iters` launches of frl_sampler_run bracketed by events on the launch stream."""
+    from flowrl_hip import _lib, _sampler
+    lib = _lib.load()
+    dev = xT.device
+    keep = []
+    desc = _sampler.build_desc(model.network, kind=_lib.FRL_KIND_DDPM, solver=_lib.FRL_SOLVER_DDPM, steps=w["T"],
+                               n_states=xT.shape[0], particles=1, x_dim=w["A"], cond_dim=w["S"],
+                               clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False)
+    fp = _sampler.build_params(model.network, model.params, dev, keep)
+    fs = _lib.FrlSchedule()
+    fs.betas, fs.alphas = model.betas.data_ptr(), model.alphas.data_ptr()
+    fs.alpha_hats, fs.postvars = model.alpha_hats.data_ptr(), model.postvars.data_ptr()
+    x0 = torch.empty_like(xT)
+    bufs = _lib.FrlFwdBufs()
+    bufs.xT, bufs.cond, bufs.noise, bufs.x0 = xT.data_ptr(), cond.data_ptr(), noise.data_ptr(), x0.data_ptr()
+    need = lib.frl_workspace_bytes(C.byref(desc))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.frl_sampler_prepare(C.byref(desc), C.byref(fp), C.byref(fs), ws.data_ptr(), need, stream))
+    for _ in range(2):
+        _lib.check(lib.frl_sampler_run(C.byref(desc), C.byref(fp), C.byref(bufs), ws.data_ptr(), need, stream))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(iters):
+        _lib.check(lib.frl_sampler_run(C.byref(desc), C.byref(fp), C.byref(bufs), ws.data_ptr(), need, stream))
+    e1.record()
+    torch.cuda.synchronize(dev)
+    flops_exec = C.c_double(0.0)
+    flops_alg = lib.frl_algorithmic_flops(C.byref(desc), C.byref(flops_exec))
+    return e0.elapsed_time(e1) / iters, flops_alg, flops_exec.value
+
+
+def cpu_baseline(w, budget_s=15.0):
+    """The numpy float32 oracle (a port of the reference's arithmetic; the JAX reference itself cannot
+    run here) timed on this box's host cores over a bounded sample of the same workload."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import flowrl_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    spec = orc.BackboneSpec(hidden_dims=w["hidden"], x_dim=w["A"], activation=w["act"], time_embedding="positional")
+    params = orc.make_params(spec, w["S"], seed=0)
+    tables = orc.ddpm_tables(w["T"], w["schedule"])
+    rng = np.random.default_rng(0)
+
+    def run(Bs):
+        xT = rng.standard_normal((Bs, w["A"])).astype(np.float32)
+        cond = rng.standard_normal((Bs, w["S"])).astype(np.float32)
+        nz = rng.standard_normal((w["T"], Bs, w["A"])).astype(np.float32)
+        t0 = time.perf_counter()
+        orc.ddpm_sample(spec, params, tables, xT, cond, nz, steps=w["T"], clip_sampler=w["clip"],
+                        x_min=w["x_min"], x_max=w["x_max"])
+        return time.perf_counter() - t0
+
+    probe_B = 4096
+    run(probe_B)                      # warm-up (BLAS threads, page faults)
+    t_probe = run(probe_B)
+    Bs = int(min(w["B"], max(probe_B, probe_B * budget_s / max(t_probe, 1e-3))))
+    Bs = max(probe_B, (Bs // 4096) * 4096)
+    t = run(Bs)
+    return {"value": Bs * w["T"] / t, "unit": "chain-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"numpy float32 oracle (oracle/flowrl_oracle.py), {Bs} of {w['B']} chains x T={w['T']}, "
+                      f"one pass, {t:.2f} s, {cores} BLAS threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override chains per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL all-gather of x0 (N>1)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    w = dict(WORKLOADS[args.workload])
+    if args.batch > 0:
+        w["B"] = args.batch
+    B, T, A, S = w["B"], w["T"], w["A"], w["S"]
+    model = build_model(w, dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    xT = torch.randn((B, A), generator=g, device=dev)
+    cond = torch.randn((B, S), generator=g, device=dev)     # this rank's shard of the states
+    noise = torch.randn((T, B, A), generator=g, device=dev)
+    gathered = torch.empty((world * B, A), device=dev) if world > 1 else None
+
+    def step():
+        _, x0, _ = model.sample(None, xT, cond, False, "ddpm", noise=noise)
+        if world > 1 and not args.no_gather:
+            dist.all_gather_into_tensor(gathered, x0)
+        return x0
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x0 = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(x0).all()
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * T / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        k_ms, flops_alg, flops_exec = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
+        achieved = flops_alg / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "action samples/sec x T steps (chain-steps/s), fused sampler, 256x3 MLP",
+            "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
+                       "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else "all_gather(x0)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "frl_sampler_g32_kernel", "kernel_ms": k_ms,
+                         "flops_algorithmic": flops_alg, "flops_executed_mfma": flops_exec,
+                         "achieved_executed": flops_exec / (k_ms * 1e-3) / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

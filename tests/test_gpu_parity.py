@@ -2,9 +2,11 @@
 inputs (params, xT, condition, externally supplied noise).
 
 Tolerance (BASELINE.json north_star: "within 1e-5 relative in fp32"), err = |hip - oracle64| / max(|oracle64|, 1):
-  * every network output of every step (eps_hist):  max err <= 1e-5
-  * chain state (x0 and every xt_hist row):         max err <= max(1e-5, 4 * e32)  and  rms err <= 2e-6
-    where e32 is the float32 ORACLE's own max deviation from the float64 oracle on the same case.
+  * every network output of every step (eps_hist):  max err <= max(1e-5, 4 * e32)
+  * chain state (x0 and every xt_hist row):         max err <= max(1e-5, 4 * e32)  and  rms err <= max(2e-6, 4 * rms32)
+    where e32 / rms32 are the float32 ORACLE's own deviations from the float64 oracle on the same case
+    (1e-5 / 2e-6 are what applies on every BASELINE config; the e32 terms only matter for ill-conditioned
+    schedules such as continuous-linear with tmax = 1, where 1/sqrt(alpha_hat_T) = 152).
     The second bound exists because the reverse chain amplifies rounding noise (vp, T=5: x0_hat is
     scaled by 1/sqrt(alpha_hat_T) = 12.5), so plain float32 arithmetic (numpy) already reaches
     5e-6..8e-6 on the worst element of some seeds; measured on MI355X the HIP path has the same rms
@@ -30,15 +32,17 @@ def _check(case, history=True):
     assert np.isfinite(x0).all()
     o32 = H.oracle_run(case, params, xT, cond, noise, dtype=np.float32)
     tol_state = max(TOL, 4.0 * max(H.rel_err(o32[0], ref0), H.rel_err(o32[1], refx)))
+    tol_rms = max(2e-6, 4.0 * max(H.rms_err(o32[0], ref0), H.rms_err(o32[1], refx)))
+    tol_eps = max(TOL, 4.0 * H.rel_err(o32[2], refe))
     e0 = H.rel_err(x0, ref0)
     msg = f"{case.name}: x0 rel err {e0:.3e} (state tol {tol_state:.1e})"
     if history:
         ee, ex = H.rel_err(eh, refe), H.rel_err(xh, refx)
         msg += f", eps_hist {ee:.3e}, xt_hist {ex:.3e}"
-        assert ee <= TOL and ex <= tol_state, msg
-        assert H.rms_err(xh, refx) <= 2e-6, msg
+        assert ee <= tol_eps and ex <= tol_state, msg
+        assert H.rms_err(xh, refx) <= tol_rms, msg
     print(msg)
-    assert e0 <= tol_state and H.rms_err(x0, ref0) <= 2e-6, msg
+    assert e0 <= tol_state and H.rms_err(x0, ref0) <= tol_rms, msg
 
 
 def test_mfma_lane_maps(lib):
