@@ -24,6 +24,8 @@
 // f = 128 g + 4 i + j sits in block (g, j), tile row i; the same map indexes the next layer's K rows,
 // so hidden-layer slab (g, j) is the row gather {128 g + 4 q + j}, done by the DMA's per-lane source
 // address.  Dense kernels are consumed in place in their Flax (in, out) row-major layout.
+#include <utility>
+
 #include "frl_internal.h"
 
 namespace frl {
@@ -32,6 +34,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FRL_ROWR(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// compile-time loop: register-array indices stay constants whatever the unroller decides
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 // ---- activations (flowrl/functional/activation.py:8-18; flax gelu tanh form) -------------------
 // exp via v_exp_f32 and reciprocal via v_rcp_f32 (1 ulp each); every form below is free of
@@ -78,21 +90,43 @@ __device__ __forceinline__ const float* pick_ptr(const float* const (&arr)[FRL_M
   return p;
 }
 
-// One hidden-layer K-slab: 16 k-steps x 8 output blocks.  `pb` = the 16 accumulator registers of
-// input block b (activated lazily, right before use, so the VALU work hides under the MFMAs).
-template <int ACT>
-__device__ __forceinline__ void hidden_slab(f32x16 (&Q)[8], const f32x16& pb, const char* lds_lane) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float bop = act_fn<ACT>(pb[r]);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const f32x4 aw = *(const f32x4*)(lds_lane + FRL_ROWR(r) * 1024 + g * 512);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        Q[g * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[j], bop, Q[g * 4 + j], 0, 0, 0);
+// One hidden Dense layer: 8 K-slabs x 16 k-steps x 8 output blocks, software-pipelined by hand: the
+// A operands (2 x ds_read_b128) and the lazily activated B operand of k-step n+1 are fetched before
+// the 8 MFMAs of k-step n are issued, also across slab boundaries (the barrier + next DMA sit between
+// the last operand fetch of a slab and its last 8 MFMAs, whose operands are already in registers).
+template <int ACT, typename NextSlab>
+__device__ __forceinline__ void hidden_layer(f32x16 (&Q)[8], const f32x16 (&P)[8], NextSlab& next_slab, unsigned lane_h) {
+  const char* sl = next_slab() + lane_h;
+  f32x4 a0 = *(const f32x4*)(sl);
+  f32x4 a1 = *(const f32x4*)(sl + 512);
+  float bop = act_fn<ACT>(P[0][0]);
+  static_for<128>([&](auto IDX) {
+    constexpr int idx = decltype(IDX)::value;
+    f32x4 n0 = a0, n1 = a1;
+    float bn = bop;
+    if constexpr (idx + 1 < 128) {
+      constexpr int nb = (idx + 1) >> 4, nr = (idx + 1) & 15;
+      if constexpr (nr == 0) sl = next_slab() + lane_h;
+      n0 = *(const f32x4*)(sl + FRL_ROWR(nr) * 1024);
+      n1 = *(const f32x4*)(sl + FRL_ROWR(nr) * 1024 + 512);
+      bn = act_fn<ACT>(P[nb][nr]);
     }
-  }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Q[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bop, Q[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Q[4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bop, Q[4 + j], 0, 0, 0);
+    // interleave: operand fetch + activation of k-step n+1 ride in the shadow of k-step n's MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 x ds_read (A operands of k-step n+1)
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (activation of k-step n+1)
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    a0 = n0; a1 = n1; bop = bn;
+  });
 }
 
 // accumulator init = bias of feature f = 128 g + 4 row(r,h) + j  (block (g,j), register r)
@@ -244,11 +278,7 @@ frl_sampler_g32_kernel(const KArgs a) {
       // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P) ; P <- Q ----------------------------
       for (int l = 1; l < a.L; ++l) {
         init_bias(Q, s_bh + (l - 1) * H, lh);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const char* sl = next_slab();
-          hidden_slab<ACT>(Q, P[b], sl + lane_h);
-        }
+        hidden_layer<ACT>(Q, P, next_slab, lane_h);
 #pragma unroll
         for (int b = 0; b < 8; ++b) P[b] = Q[b];
       }
