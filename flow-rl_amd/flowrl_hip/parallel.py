@@ -1,0 +1,58 @@
+"""Batch sharding of a sampler call over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The path shards embarrassingly: chains are independent and the 0.6-3.3 MB of
+weights are replicated, so rank r owns the contiguous block of STATES [lo, hi) — a state's particles
+stay on one GPU, its condition row is read once and best-of-N selection stays local.  The only
+collective is the final all-gather of x0 (and of the histories when requested); the reference itself
+has no distributed path (it runs one independent job per GPU, scripts/mujoco/dacer.sh:28-52).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_states: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split: the first (n_states % world) ranks own one extra state."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"rank {rank} / world {world} invalid")
+    q, r = divmod(n_states, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_ragged(local: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """All-gather along dim 0 when ranks own different row counts (pads to the largest shard; one
+    collective, sized for the point-to-point xGMI mesh: every rank sends its shard once)."""
+    world = dist.get_world_size(group)
+    mx = max(counts)
+    if all(c == mx for c in counts):
+        out = torch.empty((world * mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world, mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(world * mx, *local.shape[1:]), pad, group=group)
+    return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+
+
+def sample_sharded(sample_fn: Callable, xT: torch.Tensor, condition: Optional[torch.Tensor],
+                   noise: Optional[torch.Tensor], particles: int = 1, group=None, gather: bool = True):
+    """Run ``sample_fn(xT_shard, cond_shard, noise_shard) -> x0_shard`` on this rank's block of states and
+    all-gather the result.  Global layouts: xT (n_states*particles, A), condition (n_states, C) un-repeated,
+    noise (T, n_states*particles, A).  Every rank passes the same global tensors (or at least its own block
+    at the right offsets) and receives the full x0 when ``gather`` is set, else its own shard."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_states = xT.shape[0] // particles
+    lo, hi = shard_bounds(n_states, rank, world)
+    clo, chi = lo * particles, hi * particles
+    x0 = sample_fn(xT[clo:chi], None if condition is None else condition[lo:hi],
+                   None if noise is None else noise[:, clo:chi])
+    if world == 1 or not gather:
+        return x0
+    counts = [(shard_bounds(n_states, r, world)[1] - shard_bounds(n_states, r, world)[0]) * particles for r in range(world)]
+    return all_gather_ragged(x0, counts, group)

@@ -151,3 +151,23 @@ def test_deterministic_and_tile_independent():
     perm = np.random.default_rng(0).permutation(c.B)
     p, _, _ = H.product_run(c, model, xT[perm], cond[perm], noise[:, perm], history=False)
     assert np.array_equal(p, a[perm])
+
+
+@pytest.mark.parametrize("case", [
+    H.Case("golden_cfg1_toy2d", "ddpm", A=2, S=1, T=20, B=48, schedule="linear", clip=False, x_min=-4.0, x_max=4.0, seed=101),
+    H.Case("golden_cfg2_hopper", "ddpm", A=3, S=11, T=5, B=48, seed=102),
+    H.Case("golden_cddpm_cosine", "cddpm", A=6, S=17, T=20, B=48, temb="learnable_fourier", schedule="cosine", seed=103),
+    H.Case("golden_cnf_raw_t", "cnf", A=8, S=20, T=10, B=48, temb=None, clip=False, seed=104),
+], ids=lambda c: c.name)
+def test_against_committed_golden(case):
+    """The HIP path against the committed fixtures (tests/golden/*.npz, made by make_golden.py): no oracle run."""
+    import flowrl_oracle as orc
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / f"{case.name}.npz")
+    params = orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    model = H.product_model(case, params)
+    x0, xh, eh = H.product_run(case, model, z["xT"], z["cond"], z["noise"], history=True)
+    msg = f"{case.name}: x0 {H.rel_err(x0, z['x0']):.2e} xt {H.rel_err(xh, z['xt_hist']):.2e} eps {H.rel_err(eh, z['eps_hist']):.2e}"
+    print(msg)
+    assert H.rel_err(x0, z["x0"]) <= 2e-5 and H.rel_err(xh, z["xt_hist"]) <= 2e-5 and H.rel_err(eh, z["eps_hist"]) <= TOL, msg
+    assert H.rms_err(x0, z["x0"]) <= 2e-6, msg
