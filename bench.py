@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL all-gather of x0 (N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--act", default="", help="ablation: override the activation")
+    ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
+    ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,8 +152,21 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         w["B"] = args.batch
+    if args.act:
+        w["act"] = args.act
+    if args.layers > 0:
+        w["hidden"] = [w["hidden"][0]] * args.layers
     B, T, A, S = w["B"], w["T"], w["A"], w["S"]
     model = build_model(w, dev)
+    if args.kernel_only:
+        g = torch.Generator(device=dev).manual_seed(1234)
+        xT = torch.randn((w["B"], w["A"]), generator=g, device=dev)
+        cond = torch.randn((w["B"], w["S"]), generator=g, device=dev)
+        noise = torch.randn((w["T"], w["B"], w["A"]), generator=g, device=dev)
+        k_ms, fa, fe = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
+        print(json.dumps({"kernel_ms": k_ms, "act": w["act"], "layers": len(w["hidden"]), "alg_tflops": fa / k_ms / 1e9,
+                          "exec_tflops": fe / k_ms / 1e9}))
+        return
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     xT = torch.randn((B, A), generator=g, device=dev)
     cond = torch.randn((B, S), generator=g, device=dev)     # this rank's shard of the states

@@ -22,7 +22,9 @@ CSRC = HERE / "csrc"
 OBJ = CSRC / "_obj"
 OUT = HERE / "flowrl_hip" / "libflowrl_hip.so"
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "prepare.hip", "sampler_g32.hip"]
+# (source, object stem, extra defines); the register-streamed sampler is one translation unit per activation
+SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []), ("sampler_g32.hip", "sampler_g32", [])] + \
+          [("sampler_rs.hip", f"sampler_rs_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(6)]
 HEADERS = [CSRC / "frl_internal.h", ROOT / "include" / "flowrl_hip.h"]
 FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++17", "-Wno-unused-value",
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
@@ -42,21 +44,21 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
+def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> Path:
     OBJ.mkdir(parents=True, exist_ok=True)
     cc = hipcc()
     todo = []
     objs = []
-    for src in SOURCES:
+    for src, stem, defs in SOURCES:
         s = CSRC / src
-        o = OBJ / (s.stem + ".o")
+        o = OBJ / (stem + ".o")
         objs.append(o)
         if force or _stale(o, [s, *HEADERS, Path(__file__)]):
-            todo.append((s, o))
+            todo.append((s, o, defs))
 
     def compile_one(so):
-        s, o = so
-        cmd = [cc, *FLAGS, "-c", str(s), "-o", str(o)]
+        s, o, defs = so
+        cmd = [cc, *FLAGS, *defs, "-c", str(s), "-o", str(o)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -74,7 +76,7 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
-    ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--jobs", type=int, default=8)
     args = ap.parse_args()
     print(build(force=args.force, jobs=args.jobs))
     sys.exit(0)

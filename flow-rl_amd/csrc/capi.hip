@@ -2,6 +2,7 @@
 // Enqueue-only: no allocation, no host synchronisation, no retained pointers.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "frl_internal.h"
@@ -43,8 +44,20 @@ static int validate_desc(const FrlDesc* d) {
   // --- what this build has kernels for ---
   if (d->dtype != FRL_DTYPE_F32) { set_error("bf16 MFMA variant not built yet"); return FRL_EUNSUPPORTED; }
   for (int l = 0; l < d->n_hidden; ++l)
-    if (d->hidden[l] != G32_H) { set_error("hidden width %d: only %d-wide MLPs have a kernel in this build", d->hidden[l], G32_H); return FRL_EUNSUPPORTED; }
-  if (d->x_dim > LAST_PAD) { set_error("x_dim %d > %d", d->x_dim, LAST_PAD); return FRL_EUNSUPPORTED; }
+    if (d->hidden[l] != d->hidden[0] || (d->hidden[l] != 256 && d->hidden[l] != 512)) {
+      set_error("hidden widths must be uniform and 256 or 512 in this build (hidden[%d] = %d)", l, d->hidden[l]);
+      return FRL_EUNSUPPORTED;
+    }
+  {
+    Plan pl;
+    plan_from_desc(*d, pl);
+    const bool ok = (pl.H == 256) ? ((pl.AR <= 4 && pl.CK <= 12) || (pl.AR <= 12 && pl.CK <= 64)) : (pl.AR <= 4 && pl.CK <= 12);
+    if (!ok) {
+      set_error("x_dim %d / cond_dim %d exceed the compiled operand budgets for hidden width %d "
+                "(256: x_dim <= 24, cond_dim <= 128; 512: x_dim <= 16, cond_dim <= 48)", d->x_dim, d->cond_dim, pl.H);
+      return FRL_EUNSUPPORTED;
+    }
+  }
   return FRL_OK;
 }
 
@@ -155,11 +168,23 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.eps_hist = desc->want_history ? bufs->eps_hist : nullptr;
   for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
-  a.ws_wlp = ws + pl.off_wlp; a.ws_blp = ws + pl.off_blp;
-  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L;
+  a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
+  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H;
+  a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
-  return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
+  // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)
+  static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
+  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU)
+    return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
+  switch (desc->act) {
+    case FRL_ACT_MISH: return launch_sampler_rs_act<FRL_ACT_MISH>(a, (hipStream_t)hip_stream);
+    case FRL_ACT_SILU: return launch_sampler_rs_act<FRL_ACT_SILU>(a, (hipStream_t)hip_stream);
+    case FRL_ACT_RELU: return launch_sampler_rs_act<FRL_ACT_RELU>(a, (hipStream_t)hip_stream);
+    case FRL_ACT_GELU_TANH: return launch_sampler_rs_act<FRL_ACT_GELU_TANH>(a, (hipStream_t)hip_stream);
+    case FRL_ACT_TANH: return launch_sampler_rs_act<FRL_ACT_TANH>(a, (hipStream_t)hip_stream);
+    default: return launch_sampler_rs_act<FRL_ACT_ELU>(a, (hipStream_t)hip_stream);
+  }
 }
 
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,

@@ -33,17 +33,19 @@ enum Mode : int {
 struct Plan {
   int A, C, D, Dp;      // action dim, cond dim, time_dim, D' (= D or 1) rows of Dense_0 taken by time
   int H, L, T;
-  int XR;               // layer-0 x rows in the packed image: 8*ceil(A/8) (pairs (a, a+4) per k-step)
-  int AR;               // x registers per lane = XR/2
-  int CK;               // layer-0 cond k-steps = ceil(C/2)
-  int K0p;              // rows of the packed layer-0 image = XR + 2*CK
-  int merged;           // 1: x rows and cond rows share ONE slab (K0p <= 32)
-  int n_l0;             // layer-0 slabs
-  int NS;               // slabs per step = n_l0 + 8*(L-1) + 1
+  int TR, KS, NR;       // geometry: MFMA tile rows (32: 32x32x2, 16: 16x16x4), k per MFMA, accumulators per block
+  int XR;               // layer-0 x rows in the packed image: 4 KS ceil(A / 4KS) (row a = ROWR(r) + 4 s)
+  int AR;               // x registers per lane = XR / KS
+  int CK;               // layer-0 cond k-steps = ceil(C / KS)
+  int K0p;              // rows of the packed layer-0 image = XR + KS*CK
+  int merged;           // (LDS-slab kernel only) 1: x rows and cond rows share ONE slab (K0p <= 32)
+  int n_l0;             // (LDS-slab kernel only) layer-0 slabs
+  int NS;               // (LDS-slab kernel only) slabs per step = n_l0 + 8*(L-1) + 1
   int mode;
   long long B;
   // workspace layout (float offsets)
-  size_t off_coef, off_tb, off_w0p, off_wlp, off_blp, total_floats;
+  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, total_floats;
+  size_t w0p_rows;
 };
 
 inline int plan_from_desc(const FrlDesc& d, Plan& p) {
@@ -51,12 +53,15 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
   p.H = d.hidden[0];
-  p.XR = 8 * ((p.A + 7) / 8);
-  p.AR = p.XR / 2;
-  p.CK = (p.C + 1) / 2;
-  p.K0p = p.XR + 2 * p.CK;
+  p.TR = (p.H <= 256) ? 32 : 16;
+  p.KS = (p.TR == 32) ? 2 : 4;
+  p.NR = (p.TR == 32) ? 16 : 4;
+  p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
+  p.AR = p.XR / p.KS;
+  p.CK = (p.C + p.KS - 1) / p.KS;
+  p.K0p = p.XR + p.KS * p.CK;
   p.merged = (p.K0p <= SLAB_ROWS) ? 1 : 0;
-  p.n_l0 = p.merged ? 1 : 1 + (2 * p.CK + SLAB_ROWS - 1) / SLAB_ROWS;
+  p.n_l0 = p.merged ? 1 : 1 + (p.KS * p.CK + SLAB_ROWS - 1) / SLAB_ROWS;
   p.NS = p.n_l0 + 8 * (p.L - 1) + 1;
   p.B = (long long)d.n_states * d.particles;
   if (d.kind == FRL_KIND_DDPM) p.mode = (d.solver == FRL_SOLVER_DDIM) ? MODE_DDPM_DDIM : MODE_DDPM_DDPM;
@@ -66,8 +71,11 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };  // 256-B aligned pieces
   p.off_coef = take((size_t)p.T * COEF_STRIDE);
   p.off_tb = take((size_t)p.T * p.H);
-  p.off_w0p = take((size_t)(p.merged ? SLAB_ROWS : p.XR + (p.n_l0 - 1) * SLAB_ROWS) * p.H);
-  p.off_wlp = take((size_t)p.H * LAST_PAD);
+  p.w0p_rows = (size_t)(p.merged ? SLAB_ROWS : p.XR + (p.n_l0 - 1) * SLAB_ROWS);
+  if (p.w0p_rows < (size_t)p.K0p) p.w0p_rows = (size_t)p.K0p;
+  p.off_w0p = take(p.w0p_rows * p.H);
+  p.off_wlp = take((size_t)p.H * LAST_PAD);   // [H][32] image (LDS-slab kernel)
+  p.off_wlq = take((size_t)p.H * 64);         // per-lane packed image: H/TR * NR/4 loads x 64 lanes x 4 floats
   p.off_blp = take(LAST_PAD);
   p.total_floats = o;
   return 0;
@@ -79,9 +87,10 @@ struct KArgs {
   float* x0; float* xt_hist; float* eps_hist;
   const float* wh[FRL_MAX_HIDDEN - 1];   // Dense_1 .. Dense_{L-1} kernels (H x H), read in place
   const float* bh[FRL_MAX_HIDDEN - 1];
-  const float* ws_coef; const float* ws_tb; const float* ws_w0p; const float* ws_wlp; const float* ws_blp;
+  const float* ws_coef; const float* ws_tb; const float* ws_w0p; const float* ws_wlp; const float* ws_wlq; const float* ws_blp;
   long long B;
-  int particles, A, C, T, L, mode, clip;
+  int particles, A, C, T, L, H, mode, clip;
+  int w0p_bytes;
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;
 };
@@ -99,7 +108,8 @@ void set_error(const char* fmt, ...);
 
 // launchers implemented in the .hip files
 int launch_prepare(const PArgs& a, hipStream_t stream);
-int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);
+int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);   // LDS K-slab variant (H = 256 only), A/B reference
+template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
 int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);
 
 }  // namespace frl

@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   float* tb = ws + pl.off_tb;
   float* w0p = ws + pl.off_w0p;
   float* wlp = ws + pl.off_wlp;
+  float* wlq = ws + pl.off_wlq;
   float* blp = ws + pl.off_blp;
   float* temb = sh;                 // [T][D]
   float* h1 = sh + (size_t)T * (D > 0 ? D : 1);
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   }
 
   // ---- packed layer-0 image: rows [0, XR) = x rows (zero beyond A), then cond rows (zero beyond C) --
-  const int w0_rows = pl.merged ? SLAB_ROWS : pl.XR + (pl.n_l0 - 1) * SLAB_ROWS;
+  const int w0_rows = (int)pl.w0p_rows;
   for (int idx = tid; idx < w0_rows * H; idx += nt) {
     const int r = idx / H, f = idx - r * H;
     float v = 0.0f;
@@ -158,6 +159,19 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     wlp[idx] = (i < A) ? WL[(size_t)k * A + i] : 0.0f;
   }
   for (int i = tid; i < LAST_PAD; i += nt) blp[i] = (i < A) ? a.p.bias[pl.L][i] : 0.0f;
+  // ---- last layer, per-lane packed: load q (16 B per lane) = A operands of k-steps 4q..4q+3, k = block*NR + r,
+  //      lane (i = lane % TR, s = lane / TR) contracts feature GW*g + j + 4*(ROWR(r) + 4 s), block = 4 g + j ----
+  {
+    const int TR = pl.TR, NR = pl.NR, GW = 4 * TR;
+    for (int idx = tid; idx < HL * 64; idx += nt) {
+      const int q = idx >> 8, lane = (idx >> 2) & 63, e = idx & 3;
+      const int k = 4 * q + e, blk = k / NR, r = k - blk * NR;
+      const int rowr = (TR == 32) ? ((r & 3) + 8 * (r >> 2)) : ((r & 3) + 16 * (r >> 2));
+      const int i = lane % TR, sl = lane / TR;
+      const int kf = GW * (blk >> 2) + (blk & 3) + 4 * (rowr + 4 * sl);
+      wlq[idx] = (i < A && kf < HL) ? WL[(size_t)kf * A + i] : 0.0f;
+    }
+  }
 }
 
 int launch_prepare(const PArgs& a, hipStream_t stream) {

@@ -1,0 +1,411 @@
+// Stage 2: the persistent fused T-step sampler, exact-f32 MFMA, weights streamed L2 -> registers.
+//
+// What one launch does (reference: DDPM.sample flowrl/flow/ddpm.py:184-221, ContinuousDDPM.sample
+// continuous_ddpm.py:149-222, CNF.sample cnf.py:122-141; network ddpm.py:83-95 + mlp.py:25-33):
+//
+//   for each wave-tile of TR chains (persistent waves, one wave per SIMD, 512 registers per lane):
+//       x <- xT ; cond operands <- cond rows (broadcast over particles)
+//       for j in 0..T-1:   (all on chip)
+//           P  = tb[j] + W0x^T x + W0c^T cond                    (Dense_0; time slice pre-folded into tb)
+//           P  = b_l + W_l^T act(P)            l = 1..L-1        (hidden Dense layers)
+//           e  = b_L + W_L^T act(P)                               (Dense_L, zero-padded to TR rows)
+//           x <- update(x, e, noise[j])                           (DDPM / DDIM / Euler epilogue)
+//       x0 <- x
+//
+// Layout.  Everything is computed TRANSPOSED: an MFMA tile is [TR output features] x [TR chains], a
+// chain lives on a lane (column = lane % TR) and the f32 MFMA leaves feature row(r, s) = ROWR(r) + 4 s
+// of the tile in accumulator register r of lane group s = lane / TR.  The B operand of the same
+// instruction wants k-slot s on lane group s, so accumulator register r of a finished layer IS the B
+// operand of the next layer's k-step that contracts the KS features {row(r, s)}: activations never
+// leave the register file — no LDS bounce, no lane permute between layers.  Output feature
+// f = GW g + 4 i + j sits in block (g, j), tile row i (one 16-byte A-operand load feeds the 4 blocks
+// j = 0..3 of group g), and the same map indexes the next layer's K rows.
+//
+// Two geometries share this file:
+//   TR = 32: v_mfma_f32_32x32x2_f32, KS = 2, 16 accumulator registers per block, H <= 256
+//   TR = 16: v_mfma_f32_16x16x4_f32, KS = 4,  4 accumulator registers per block, H <= 512
+// Both keep H/2 resp. H/4 registers of activations in and as many accumulators out per lane.
+//
+// Weights are read IN PLACE (Flax (in, out) row-major) straight into registers with
+// buffer_load_dwordx4 (per-lane row = the k-slot's feature row, scalar offset = the k-step), a ring of
+// RING k-steps ahead of the MFMAs; they are L2-resident (0.6-3.3 MB) and the four waves of a CU read
+// the same lines at nearly the same time.  There is no LDS weight staging and no barrier in the main
+// loop (the LDS-DMA K-slab variant, sampler_g32.hip, loses ~1.2k cycles per 32 KB slab to DMA issue
+// and barrier skew — A/B in DESIGN.md); LDS only holds the small bias / coefficient tables.
+#include <utility>
+
+#include "frl_internal.h"
+
+namespace frl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int... I, typename F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time loop: register-array indices stay constants whatever the unroller decides
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int TR>
+struct Geo;
+template <>
+struct Geo<32> {
+  static constexpr int KS = 2, NR = 16, RING = 4;
+  typedef f32x16 acc_t;
+  static constexpr int rowr(int r) { return (r & 3) + 8 * (r >> 2); }
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Geo<16> {
+  static constexpr int KS = 4, NR = 4, RING = 2;
+  typedef f32x4 acc_t;
+  static constexpr int rowr(int r) { return (r & 3) + 16 * (r >> 2); }
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// ---- activations (flowrl/functional/activation.py:8-18; flax gelu tanh form) -------------------
+// exp via v_exp_f32 and reciprocal via v_rcp_f32 (1 ulp each); every form below is free of
+// cancellation so the relative error stays at a few ulp over the whole range.
+template <int ACT>
+__device__ __forceinline__ float act_fn(float x) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  if constexpr (ACT == FRL_ACT_MISH) {
+    // x * tanh(softplus(x)) == x * n / (n + 2),  n = e^x (e^x + 2)
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -88.0f, 20.0f) * LOG2E);
+    const float n = e * (e + 2.0f);
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
+  } else if constexpr (ACT == FRL_ACT_SILU) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-x, -88.0f, 80.0f) * LOG2E);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+  } else if constexpr (ACT == FRL_ACT_RELU) {
+    return fmaxf(x, 0.0f);
+  } else if constexpr (ACT == FRL_ACT_GELU_TANH) {
+    // 0.5 x (1 + tanh(u)) == x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+    const float u = 0.7978845608028654f * (x + 0.044715f * (x * x * x));
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-2.0f * u, -88.0f, 80.0f) * LOG2E);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+  } else if constexpr (ACT == FRL_ACT_TANH) {
+    const float t = __builtin_amdgcn_exp2f(-2.0f * LOG2E * fabsf(x));
+    const float y = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    return copysignf(y, x);
+  } else {  // ELU
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.0f) * LOG2E);
+    return x > 0.0f ? x : e - 1.0f;
+  }
+}
+
+__device__ __forceinline__ f32x4 ldw(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+__device__ __forceinline__ const float* pick_ptr_rs(const float* const (&arr)[FRL_MAX_HIDDEN - 1], int idx) {
+  const float* p = arr[0];
+#pragma unroll
+  for (int k = 1; k < FRL_MAX_HIDDEN - 1; ++k) p = (idx == k) ? arr[k] : p;
+  return p;
+}
+
+template <int TR, int H, int ACT, int NRX, int CKMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+frl_sampler_rs_kernel(const KArgs a) {
+  typedef Geo<TR> G;
+  typedef typename G::acc_t acc_t;
+  constexpr int KS = G::KS, NR = G::NR, RING = G::RING;
+  constexpr int NB = H / TR;        // output (and input) feature blocks per hidden layer
+  constexpr int NG = NB / 4;        // 16-byte A-operand loads per k-step
+  constexpr int GW = 4 * TR;        // features per load group
+  constexpr int NK = NB * NR;       // k-steps per hidden layer
+  constexpr int ROWB = H * 4;       // bytes per weight row
+  constexpr int RINGL = 8;          // last-layer operand ring (one 16-byte load = 4 k-steps)
+  static_assert(NB % 4 == 0 && NK % RING == 0 && (NK / 4) % RINGL == 0, "geometry");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int li = lane % TR, ls = lane / TR;
+
+  float* s_tb = (float*)smem;                         // [T][H]  layer-0 bias table (time slice folded in)
+  float* s_bh = s_tb + a.T * H;                       // [L-1][H] hidden biases
+  float* s_bl = s_bh + (a.L - 1) * H;                 // [32]    padded last-layer bias
+  float* s_coef = s_bl + LAST_PAD;                    // [T][8]
+  for (int idx = tid; idx < a.T * H; idx += blockDim.x) s_tb[idx] = a.ws_tb[idx];
+  for (int l = 1; l < a.L; ++l) {
+    const float* bp = pick_ptr_rs(a.bh, l - 1);
+    for (int idx = tid; idx < H; idx += blockDim.x) s_bh[(l - 1) * H + idx] = bp[idx];
+  }
+  if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
+  for (int idx = tid; idx < a.T * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
+  __syncthreads();
+
+  // per-lane parts of the weight addresses (bytes)
+  const unsigned voff_h = ls * (16 * ROWB) + li * 16;   // hidden: row = GWg + j + 4 ROWR(r) + 16 s
+  const unsigned voff_x = ls * (4 * ROWB) + li * 16;    // Dense_0 x rows: row = ROWR(r) + 4 s
+  const unsigned voff_c = ls * ROWB + li * 16;          // Dense_0 cond rows: row = XR + KS c + s
+  const unsigned voff_l = lane * 16;                    // Dense_L: per-lane packed image
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_w0p, 0, a.w0p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_wlq, 0, NK * 64 * 4, 0x00020000);
+
+  auto bias_init = [&](acc_t (&Q)[NB], const float* sb) {
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      sfor<NR>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const f32x4 bv = *(const f32x4*)(sb + g * GW + 4 * (G::rowr(r) + 4 * ls));
+        sfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; Q[g * 4 + j][r] = bv[j]; });
+      });
+    });
+  };
+
+  // hidden-layer operand ring: slot (k % RING) holds the NG loads of k-step k
+  f32x4 ring[RING][NG];
+  auto hload = [&](__amdgpu_buffer_rsrc_t rs, auto KI) {
+    constexpr int k = decltype(KI)::value % NK;
+    constexpr int b = k / NR, r = k % NR;
+    constexpr int soff = (GW * (b >> 2) + (b & 3) + 4 * G::rowr(r)) * ROWB;
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      ring[k % RING][g] = ldw(rs, voff_h + g * (GW * 4), soff);
+    });
+  };
+
+  acc_t P[NB], Q[NB];
+  const int n_wt = (int)((a.B + TR - 1) / TR);
+
+  for (int wt = blockIdx.x * nw + wave; wt < n_wt; wt += gridDim.x * nw) {
+    const long long chain = (long long)wt * TR + li;
+    const bool valid = chain < a.B;
+    const long long state = (a.particles == 1) ? chain : chain / a.particles;
+
+    float xs[NRX];      // chain state x^T: register r holds action row a = row(r, s)
+    sfor<NRX>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      const int ai = G::rowr(r) + 4 * ls;
+      xs[r] = (valid && ai < a.A) ? a.xT[chain * a.A + ai] : 0.0f;
+    });
+    float cb[CKMAX];    // cond operands: k-step c contracts cond features KS c + s
+    sfor<CKMAX>([&](auto CI) {
+      constexpr int c = decltype(CI)::value;
+      const int k = KS * c + ls;
+      cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
+    });
+
+    for (int j = 0; j < a.T; ++j) {
+      // noise for this step: issued now, consumed after the last layer
+      float zr[NRX];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+      });
+
+      // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
+      {
+        constexpr int N0 = NRX + CKMAX;       // compile-time k-step slots; slot n is live iff n0_live(n)
+        f32x4 r0[RING][NG];
+        auto live = [&](int n) { return n < NRX ? n < a.AR : (n - NRX) < a.CK; };
+        auto l0load = [&](auto NI) {
+          constexpr int n = decltype(NI)::value;
+          if (live(n)) {
+            sfor<NG>([&](auto GI) {
+              constexpr int g = decltype(GI)::value;
+              if constexpr (n < NRX) r0[n % RING][g] = ldw(rs0, voff_x + g * (GW * 4), G::rowr(n) * ROWB);
+              else r0[n % RING][g] = ldw(rs0, voff_c + g * (GW * 4), (a.XR + KS * (n - NRX)) * ROWB);
+            });
+          }
+        };
+        sfor<RING - 1>([&](auto NI) { l0load(NI); });
+        if (a.L > 1) {   // first hidden layer's operands: in flight under Dense_0
+          const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh[0], 0, H * ROWB, 0x00020000);
+          sfor<RING - 1>([&](auto KI) { hload(rs1, KI); });
+        }
+        bias_init(P, s_tb + j * H);
+        sfor<N0>([&](auto NI) {
+          constexpr int n = decltype(NI)::value;
+          if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});
+          if (live(n)) {
+            float bop;
+            if constexpr (n < NRX) bop = xs[n]; else bop = cb[n - NRX];
+            sfor<NG>([&](auto GI) {
+              constexpr int g = decltype(GI)::value;
+              const f32x4 aw = r0[n % RING][g];
+              sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj] = G::mfma(aw[jj], bop, P[g * 4 + jj]); });
+            });
+          }
+        });
+      }
+
+      // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P) ; P <- Q ----------------------------
+      for (int l = 1; l < a.L; ++l) {
+        // operands of this layer's first RING-1 k-steps are already in flight; the tail prefetches the next layer
+        const float* wn = pick_ptr_rs(a.wh, (l + 1 < a.L) ? l : l - 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)wn, 0, H * ROWB, 0x00020000);
+        bias_init(Q, s_bh + (l - 1) * H);
+        float bop = act_fn<ACT>(P[0][0]);
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
+          else hload(rsn, std::integral_constant<int, k + RING - 1>{});
+          float bn = bop;
+          if constexpr (k + 1 < NK) bn = act_fn<ACT>(P[(k + 1) / NR][(k + 1) % NR]);
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const f32x4 aw = ring[k % RING][g];
+            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; Q[g * 4 + jj] = G::mfma(aw[jj], bop, Q[g * 4 + jj]); });
+          });
+          // operand fetch + activation of later k-steps ride in the shadow of this k-step's MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);   // VMEM reads (A operands, RING-1 k-steps ahead)
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // VALU (activation of k-step k+1)
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NB - 4, 0);
+          __builtin_amdgcn_sched_barrier(0);   // one scheduling region per k-step (the group solver is superlinear)
+          bop = bn;
+        });
+        sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; P[b] = Q[b]; });
+      }
+
+      // ---------------- Dense_L : O = b_L + W_L^T act(P), padded to TR rows --------------------------
+      acc_t O;
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[G::rowr(r) + 4 * ls]; });
+      {
+        constexpr int NLD = NK / 4;    // 16-byte loads: load q covers k-steps 4q .. 4q+3
+        f32x4 rl[RINGL];
+        sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
+        float bop = act_fn<ACT>(P[0][0]);
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
+            rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsl, voff_l, (k / 4 + RINGL - 1) * 1024);
+          float bn = bop;
+          if constexpr (k + 1 < NK) bn = act_fn<ACT>(P[(k + 1) / NR][(k + 1) % NR]);
+          O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
+          bop = bn;
+        });
+      }
+
+      // ---------------- epilogue: one reverse-diffusion / Euler step ---------------------------------
+      const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
+      const float c2 = s_coef[j * COEF_STRIDE + 2], c3 = s_coef[j * COEF_STRIDE + 3];
+      const float c4 = s_coef[j * COEF_STRIDE + 4], c5 = s_coef[j * COEF_STRIDE + 5];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        const bool in = valid && ai < a.A;
+        const float eps = O[r], xt = xs[r];
+        if (a.xt_hist != nullptr && in) {
+          const long long o = ((long long)j * a.B + chain) * a.A + ai;
+          a.xt_hist[o] = xt;
+          a.eps_hist[o] = eps;
+        }
+        float xn;
+        if (a.mode == MODE_DDPM_DDPM) {
+          float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);   // ddpm.py:200-201
+          xn = c2 * (c3 * x0h + c4 * xt);                           // ddpm.py:202-203
+          xn += c5 * zr[r];                                         // ddpm.py:206
+        } else if (a.mode == MODE_DDPM_DDIM) {
+          xn = c0 * (xt - c1 * eps) + c2 * eps;                     // ddpm.py:211
+          if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+        } else if (a.mode == MODE_CDDPM_DDPM) {
+          float x0h = (xt - c1 * eps) / c0;                         // continuous_ddpm.py:165
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * x0h + c3 * xt;                                  // :173
+          xn += c5 * zr[r];                                         // :174
+        } else if (a.mode == MODE_CDDPM_DDIM) {
+          float x0h = (xt - c1 * eps) / c0;
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * x0h + c3 * eps;                                 // :177
+        } else {
+          xn = xt + eps / c0;                                       // cnf.py:108
+          if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+        }
+        xs[r] = in ? xn : 0.0f;
+      });
+    }
+
+    sfor<NRX>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      const int ai = G::rowr(r) + 4 * ls;
+      if (valid && ai < a.A) a.x0[chain * a.A + ai] = xs[r];
+    });
+  }
+}
+
+// ---- launcher --------------------------------------------------------------------------------------
+static int device_cus_rs() {
+  static thread_local int cus[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+template <int TR, int H, int ACT, int NRX, int CKMAX>
+static int launch_inst(const KArgs& a, hipStream_t stream) {
+  auto kern = frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX>;
+  const int ncu = device_cus_rs();
+  const long long n_wt = (a.B + TR - 1) / TR;
+  long long per_cu = (n_wt + ncu - 1) / ncu;
+  int nw = (int)(per_cu < 1 ? 1 : (per_cu > MAX_WAVES ? MAX_WAVES : per_cu));
+  if (nw == 3) nw = 4;
+  long long nwg = (n_wt + nw - 1) / nw;
+  const int grid = (int)(nwg < ncu ? nwg : ncu);
+  const size_t lds = sizeof(float) * ((size_t)a.T * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.T * COEF_STRIDE);
+  if (lds > 160 * 1024) { set_error("sampler: steps=%d needs %zu B of LDS (> 160 KiB)", a.T, lds); return FRL_EUNSUPPORTED; }
+  static thread_local size_t configured[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && configured[dev] < lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
+    configured[dev] = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+template <int ACT>
+int launch_sampler_rs_act(const KArgs& a, hipStream_t stream) {
+#ifndef FRL_RS_SKIP_A
+  if (a.H == 256 && a.AR <= 4 && a.CK <= 12) return launch_inst<32, 256, ACT, 4, 12>(a, stream);
+#endif
+#ifndef FRL_RS_SKIP_B
+  if (a.H == 256 && a.AR <= 12 && a.CK <= 64) return launch_inst<32, 256, ACT, 12, 64>(a, stream);
+#endif
+#ifndef FRL_RS_SKIP_C
+  if (a.H == 512 && a.AR <= 4 && a.CK <= 12) return launch_inst<16, 512, ACT, 4, 12>(a, stream);
+#endif
+  set_error("no compiled kernel for hidden width %d with x_dim %d / cond_dim %d", a.H, a.A, a.C);
+  return FRL_EUNSUPPORTED;
+}
+
+#ifndef FRL_RS_ACT
+#error "compile with -DFRL_RS_ACT=<FRL_ACT_*>: one translation unit per activation"
+#endif
+template int launch_sampler_rs_act<FRL_RS_ACT>(const KArgs&, hipStream_t);
+
+}  // namespace frl

@@ -119,6 +119,28 @@ def test_cnf_euler_clip_positional():
     _check(H.Case("cnf-clip", "cnf", A=3, S=11, T=10, B=100, clip=True, seed=12))
 
 
+def test_cnf_fql_512x4_gelu():
+    # cfg3 shape: FQL flow policy, obs 39, act 8, 512x4 gelu(tanh), raw time, 10 Euler steps (16x16x4 MFMA geometry)
+    for B in (16, 200):
+        _check(H.Case(f"cfg3-fql-B{B}", "cnf", A=8, S=39, T=10, B=B, hidden=(512, 512, 512, 512), act="gelu_tanh",
+                      temb=None, clip=False, seed=20 + B))
+
+
+def test_ddpm_512x2_mish_positional():
+    _check(H.Case("ddpm-512x2", "ddpm", A=3, S=11, T=5, B=100, hidden=(512, 512), seed=23))
+
+
+def test_cddpm_humanoid_wide_operands():
+    # cfg4 operand sizes without the cond-embedding MLP: act 17, 128 condition features, 256x3, T=20, 8 particles/state
+    _check(H.Case("cfg4-operands", "cddpm", A=17, S=128, T=20, B=24 * 8, particles=8, temb="learnable_fourier",
+                  schedule="cosine", seed=24))
+
+
+@pytest.mark.parametrize("act", ["gelu_tanh", "tanh", "elu", "silu", "relu"])
+def test_all_activations(act):
+    _check(H.Case(f"act-{act}", "ddpm", A=3, S=11, T=5, B=96, hidden=(256, 256), act=act, seed=30))
+
+
 def test_no_history_matches_history():
     c = H.Case("nohist", "ddpm", A=3, S=11, T=5, B=300, seed=13)
     params, xT, cond, noise = H.make_inputs(c)
