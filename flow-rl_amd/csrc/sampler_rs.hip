@@ -38,6 +38,7 @@
 
 namespace frl {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -101,6 +102,40 @@ __device__ __forceinline__ float act_fn(float x) {
   } else {  // ELU
     const float e = __builtin_amdgcn_exp2f(fminf(x, 0.0f) * LOG2E);
     return x > 0.0f ? x : e - 1.0f;
+  }
+}
+
+// Two activations at once: the plain multiply/add/fma steps become v_pk_*_f32 (one issue slot for both).
+// The f32 MFMA shares the vector ALU, so VALU work is NOT hidden behind it (measured: +4.3..6.5 cycles per
+// plain VALU, +9..12 per transcendental beside v_mfma_f32_32x32x2_f32; v_pk_fma_f32 costs what v_fma_f32 does).
+template <int ACT>
+__device__ __forceinline__ f32x2 act_fn2(f32x2 x) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  if constexpr (ACT == FRL_ACT_MISH) {
+    f32x2 c = {__builtin_amdgcn_fmed3f(x[0], -88.0f, 20.0f), __builtin_amdgcn_fmed3f(x[1], -88.0f, 20.0f)};
+    c = c * LOG2E;
+    const f32x2 e = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
+    const f32x2 u = e + 2.0f;
+    const f32x2 n = e * u;
+    const f32x2 d = e * u + 2.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * (n * r);
+  } else if constexpr (ACT == FRL_ACT_SILU) {
+    f32x2 c = {__builtin_amdgcn_fmed3f(-x[0], -88.0f, 80.0f), __builtin_amdgcn_fmed3f(-x[1], -88.0f, 80.0f)};
+    c = c * LOG2E;
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])} + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+  } else if constexpr (ACT == FRL_ACT_GELU_TANH) {
+    const f32x2 x2 = x * x;
+    const f32x2 u = (x2 * (0.044715f * -2.0f * 0.7978845608028654f) + (-2.0f * 0.7978845608028654f)) * x;   // -2u
+    f32x2 c = {__builtin_amdgcn_fmed3f(u[0], -88.0f, 80.0f), __builtin_amdgcn_fmed3f(u[1], -88.0f, 80.0f)};
+    c = c * LOG2E;
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])} + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+  } else {
+    return f32x2{act_fn<ACT>(x[0]), act_fn<ACT>(x[1])};
   }
 }
 
@@ -180,8 +215,28 @@ frl_sampler_rs_kernel(const KArgs a) {
     });
   };
 
+  // Dense_0 operand ring (x rows then cond rows).  Loads are unconditional (dead slots read rows nobody uses;
+  // the descriptor bounds-checks) so that the vmcnt bookkeeping stays exact across the uniform `live` branches.
+  constexpr int N0 = NRX + CKMAX;       // compile-time k-step slots; slot n is live iff live(n)
+  f32x4 r0[RING][NG];
+  auto live = [&](int n) { return n < NRX ? n < a.AR : (n - NRX) < a.CK; };
+  auto l0load = [&](auto NI) {
+    constexpr int n = decltype(NI)::value;
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      if constexpr (n < NRX) r0[n % RING][g] = ldw(rs0, voff_x + g * (GW * 4), G::rowr(n) * ROWB);
+      else r0[n % RING][g] = ldw(rs0, voff_c + g * (GW * 4), (a.XR + KS * (n - NRX)) * ROWB);
+    });
+  };
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.L > 1 ? a.wh[0] : a.ws_w0p), 0, H * ROWB, 0x00020000);
+
   acc_t P[NB], Q[NB];
   const int n_wt = (int)((a.B + TR - 1) / TR);
+
+  // Weight operands never depend on the data, so the first ring entries of Dense_0 and of the first hidden layer
+  // are fetched one step ahead (before the previous step's Dense_L) and stay valid across steps and tiles.
+  sfor<RING - 1>([&](auto NI) { l0load(NI); });
+  if (a.L > 1) sfor<RING - 1>([&](auto KI) { hload(rs1, KI); });
 
   for (int wt = blockIdx.x * nw + wave; wt < n_wt; wt += gridDim.x * nw) {
     const long long chain = (long long)wt * TR + li;
@@ -202,101 +257,86 @@ frl_sampler_rs_kernel(const KArgs a) {
     });
 
     for (int j = 0; j < a.T; ++j) {
-      // noise for this step: issued now, consumed after the last layer
+      // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
+      bias_init(P, s_tb + j * H);
+      sfor<N0>([&](auto NI) {
+        constexpr int n = decltype(NI)::value;
+        if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});
+        if (live(n)) {
+          float bop;
+          if constexpr (n < NRX) bop = xs[n]; else bop = cb[n - NRX];
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const f32x4 aw = r0[n % RING][g];
+            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj] = G::mfma(aw[jj], bop, P[g * 4 + jj]); });
+          });
+        }
+      });
+
+      // noise for this step and the first Dense_L operands: issued now, consumed after the hidden layers
       float zr[NRX];
       sfor<NRX>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
         const int ai = G::rowr(r) + 4 * ls;
         zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
       });
-
-      // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
-      {
-        constexpr int N0 = NRX + CKMAX;       // compile-time k-step slots; slot n is live iff n0_live(n)
-        f32x4 r0[RING][NG];
-        auto live = [&](int n) { return n < NRX ? n < a.AR : (n - NRX) < a.CK; };
-        auto l0load = [&](auto NI) {
-          constexpr int n = decltype(NI)::value;
-          if (live(n)) {
-            sfor<NG>([&](auto GI) {
-              constexpr int g = decltype(GI)::value;
-              if constexpr (n < NRX) r0[n % RING][g] = ldw(rs0, voff_x + g * (GW * 4), G::rowr(n) * ROWB);
-              else r0[n % RING][g] = ldw(rs0, voff_c + g * (GW * 4), (a.XR + KS * (n - NRX)) * ROWB);
-            });
-          }
-        };
-        sfor<RING - 1>([&](auto NI) { l0load(NI); });
-        if (a.L > 1) {   // first hidden layer's operands: in flight under Dense_0
-          const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh[0], 0, H * ROWB, 0x00020000);
-          sfor<RING - 1>([&](auto KI) { hload(rs1, KI); });
-        }
-        bias_init(P, s_tb + j * H);
-        sfor<N0>([&](auto NI) {
-          constexpr int n = decltype(NI)::value;
-          if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});
-          if (live(n)) {
-            float bop;
-            if constexpr (n < NRX) bop = xs[n]; else bop = cb[n - NRX];
-            sfor<NG>([&](auto GI) {
-              constexpr int g = decltype(GI)::value;
-              const f32x4 aw = r0[n % RING][g];
-              sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj] = G::mfma(aw[jj], bop, P[g * 4 + jj]); });
-            });
-          }
-        });
-      }
+      constexpr int NLD = NK / 4;    // Dense_L: 16-byte loads, load q covers k-steps 4q .. 4q+3
+      f32x4 rl[RINGL];
+      sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
 
       // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P) ; P <- Q ----------------------------
       for (int l = 1; l < a.L; ++l) {
-        // operands of this layer's first RING-1 k-steps are already in flight; the tail prefetches the next layer
-        const float* wn = pick_ptr_rs(a.wh, (l + 1 < a.L) ? l : l - 1);
+        // operands of this layer's first RING-1 k-steps are already in flight; the tail prefetches the next
+        // layer's — after the last hidden layer that is the FIRST hidden layer again (next step / next tile)
+        const float* wn = pick_ptr_rs(a.wh, (l + 1 < a.L) ? l : 0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)wn, 0, H * ROWB, 0x00020000);
         bias_init(Q, s_bh + (l - 1) * H);
-        float bop = act_fn<ACT>(P[0][0]);
+        // activations are computed two at a time on the even/odd register pair (2m, 2m+1) (an aligned pair, so
+        // the packed ops need no moves), one k-step before the first of the two is consumed
+        float bop, bn1, bn2 = 0.0f;
+        { const f32x2 y = act_fn2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
           else hload(rsn, std::integral_constant<int, k + RING - 1>{});
-          float bn = bop;
-          if constexpr (k + 1 < NK) bn = act_fn<ACT>(P[(k + 1) / NR][(k + 1) % NR]);
+          if constexpr ((k & 1) == 1 && k + 2 < NK) {
+            const f32x2 y = act_fn2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            bn1 = y[0]; bn2 = y[1];
+          }
           sfor<NG>([&](auto GI) {
             constexpr int g = decltype(GI)::value;
             const f32x4 aw = ring[k % RING][g];
             sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; Q[g * 4 + jj] = G::mfma(aw[jj], bop, Q[g * 4 + jj]); });
           });
-          // operand fetch + activation of later k-steps ride in the shadow of this k-step's MFMAs
+          // issue order inside the k-step: first MFMA, then the operand loads (RING-1 k-steps ahead)
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);   // VMEM reads (A operands, RING-1 k-steps ahead)
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // VALU (activation of k-step k+1)
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, NB - 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);   // VMEM reads
           __builtin_amdgcn_sched_barrier(0);   // one scheduling region per k-step (the group solver is superlinear)
-          bop = bn;
+          bop = bn1; bn1 = bn2;
         });
         sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; P[b] = Q[b]; });
       }
+
+      // next step's (or next tile's) first Dense_0 operands: in flight under Dense_L and the epilogue
+      sfor<RING - 1>([&](auto NI) { l0load(NI); });
 
       // ---------------- Dense_L : O = b_L + W_L^T act(P), padded to TR rows --------------------------
       acc_t O;
       sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[G::rowr(r) + 4 * ls]; });
       {
-        constexpr int NLD = NK / 4;    // 16-byte loads: load q covers k-steps 4q .. 4q+3
-        f32x4 rl[RINGL];
-        sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
-        float bop = act_fn<ACT>(P[0][0]);
+        float bop, bn1, bn2 = 0.0f;
+        { const f32x2 y = act_fn2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
             rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsl, voff_l, (k / 4 + RINGL - 1) * 1024);
-          float bn = bop;
-          if constexpr (k + 1 < NK) bn = act_fn<ACT>(P[(k + 1) / NR][(k + 1) % NR]);
+          if constexpr ((k & 1) == 1 && k + 2 < NK) {
+            const f32x2 y = act_fn2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            bn1 = y[0]; bn2 = y[1];
+          }
           O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
-          bop = bn;
+          bop = bn1; bn1 = bn2;
         });
       }
 
