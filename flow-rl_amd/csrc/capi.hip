@@ -41,6 +41,10 @@ static int validate_desc(const FrlDesc* d) {
   if (d->act < FRL_ACT_MISH || d->act > FRL_ACT_ELU) { set_error("act %d invalid", d->act); return FRL_EINVAL; }
   if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
   if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
+  if (d->cond_embed) {
+    if (d->cond_dim != COND_EMBED_DIM) { set_error("cond_embed: cond_dim must be %d (MLP(128,128)), got %d", COND_EMBED_DIM, d->cond_dim); return FRL_EUNSUPPORTED; }
+    if (d->cond_in_dim < 1) { set_error("cond_embed: cond_in_dim %d invalid", d->cond_in_dim); return FRL_EINVAL; }
+  }
   // --- what this build has kernels for ---
   if (d->dtype != FRL_DTYPE_F32) { set_error("bf16 MFMA variant not built yet"); return FRL_EUNSUPPORTED; }
   for (int l = 0; l < d->n_hidden; ++l)
@@ -93,6 +97,7 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
   const int A = desc->x_dim, C = desc->cond_dim;
   const int Dp = desc->time_embed == FRL_TEMB_NONE ? 1 : desc->time_dim;
   double macs = (double)(A + Dp + C) * desc->hidden[0];
+  const double cond_flops = desc->cond_embed ? 2.0 * (double)desc->n_states * ((double)desc->cond_in_dim * COND_EMBED_DIM + (double)COND_EMBED_DIM * COND_EMBED_DIM) : 0.0;
   for (int l = 1; l < desc->n_hidden; ++l) macs += (double)desc->hidden[l - 1] * desc->hidden[l];
   macs += (double)desc->hidden[desc->n_hidden - 1] * A;
   if (executed != nullptr) {
@@ -101,9 +106,9 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     double em = (double)(pl.XR + 2 * pl.CK) * pl.H;             // Dense_0 without the hoisted time slice, padded
     for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
     em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
-    *executed = 2.0 * B * T * em;
+    *executed = 2.0 * B * T * em + cond_flops;
   }
-  return 2.0 * B * T * macs;
+  return 2.0 * B * T * macs + cond_flops;
 }
 
 int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
@@ -142,7 +147,7 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
 }
 
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
-                    const void* workspace, size_t workspace_bytes, void* hip_stream) {
+                    void* workspace, size_t workspace_bytes, void* hip_stream) {
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
@@ -158,11 +163,22 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   if (desc->want_history && (bufs->xt_hist == nullptr || bufs->eps_hist == nullptr)) { set_error("want_history set but xt_hist / eps_hist is NULL"); return FRL_EINVAL; }
   for (int l = 1; l < desc->n_hidden; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->cond_embed)
+    for (int k = 0; k < 2; ++k)
+      if (params->cond_kernel[k] == nullptr || params->cond_bias[k] == nullptr) { set_error("params.cond_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
 
   const float* ws = (const float*)workspace;
   KArgs a;
   memset(&a, 0, sizeof(a));
   a.xT = bufs->xT; a.cond = bufs->cond; a.noise = needs_noise ? bufs->noise : nullptr;
+  if (desc->cond_embed) {
+    // cond_embedding MLP once per state (ddpm.py:89-90), into the workspace; the sampler then reads those rows
+    float* cfeat = (float*)workspace + pl.off_cfeat;
+    rc = launch_cond_embed(desc->act, bufs->cond, desc->n_states, desc->cond_in_dim, params->cond_kernel[0], params->cond_bias[0],
+                           params->cond_kernel[1], params->cond_bias[1], cfeat, (hipStream_t)hip_stream);
+    if (rc != FRL_OK) return rc;
+    a.cond = cfeat;
+  }
   a.x0 = bufs->x0;
   a.xt_hist = desc->want_history ? bufs->xt_hist : nullptr;
   a.eps_hist = desc->want_history ? bufs->eps_hist : nullptr;

@@ -18,6 +18,7 @@ constexpr int SLAB_ROWS = 32;
 constexpr int NBUF = 2;               // LDS slab ring depth
 constexpr int COEF_STRIDE = 8;        // floats per step in the coefficient table
 constexpr int MAX_WAVES = 4;          // waves per workgroup (one per SIMD)
+constexpr int COND_EMBED_DIM = 128;   // width of both cond_embedding layers in every reference agent
 constexpr int LAST_PAD = 32;          // last layer is zero-padded to 32 output rows (one MFMA block)
 
 // per-step update modes (ws coef table is built for exactly one of them)
@@ -44,7 +45,7 @@ struct Plan {
   int mode;
   long long B;
   // workspace layout (float offsets)
-  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, total_floats;
+  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, total_floats;
   size_t w0p_rows;
 };
 
@@ -77,6 +78,7 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.off_wlp = take((size_t)p.H * LAST_PAD);   // [H][32] image (LDS-slab kernel)
   p.off_wlq = take((size_t)p.H * 64);         // per-lane packed image: H/TR * NR/4 loads x 64 lanes x 4 floats
   p.off_blp = take(LAST_PAD);
+  p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
   p.total_floats = o;
   return 0;
 }
@@ -110,6 +112,8 @@ void set_error(const char* fmt, ...);
 int launch_prepare(const PArgs& a, hipStream_t stream);
 int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);   // LDS K-slab variant (H = 256 only), A/B reference
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
+int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim, const float* w0, const float* b0,
+                       const float* w1, const float* b1, float* cfeat, hipStream_t stream);
 int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);
 
 }  // namespace frl

@@ -59,8 +59,12 @@ def _split_condition(xT: torch.Tensor, condition: Optional[torch.Tensor], partic
 def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, particles: int, x_dim: int,
                cond_dim: int, clip_sampler: bool, x_min, x_max, want_history: bool) -> _lib.FrlDesc:
     pred = network.predictor
-    if network.cond_embedding is not None:
-        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "cond_embedding MLP is not in the fused path yet")
+    ce = network.cond_embedding
+    if ce is not None:
+        if (list(ce.hidden_dims) != [128, 128] or ce.output_dim or ce.layer_norm or (ce.dropout and ce.dropout > 0)
+                or ce.act_name != pred.act_name):
+            raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED,
+                                            "cond_embedding must be MLP(hidden_dims=(128, 128), activation=<predictor's>) as in the reference agents")
     if pred.layer_norm or (pred.dropout and pred.dropout > 0):
         raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "layer_norm / dropout>0 backbones are outside the fused path")
     if len(pred.hidden_dims) < 1 or len(pred.hidden_dims) > _lib.FRL_MAX_HIDDEN:
@@ -69,7 +73,11 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
     d.abi_version = _lib.FRL_ABI_VERSION
     d.kind, d.solver, d.steps = kind, solver, steps
     d.n_states, d.particles = n_states, particles
-    d.x_dim, d.cond_dim = x_dim, cond_dim
+    d.x_dim = x_dim
+    if ce is not None:
+        d.cond_embed, d.cond_in_dim, d.cond_dim = 1, cond_dim, 128
+    else:
+        d.cond_embed, d.cond_in_dim, d.cond_dim = 0, 0, cond_dim
     te = network.time_embedding
     if te is None:
         d.time_embed, d.time_dim = _lib.FRL_TEMB_NONE, 0
@@ -118,12 +126,23 @@ def build_params(network, params: Dict, device: torch.device, keep: list) -> _li
     for i in range(n + 1):
         fp.kernel[i] = leaf((network.predictor_name, f"Dense_{i}", "kernel"))
         fp.bias[i] = leaf((network.predictor_name, f"Dense_{i}", "bias"))
+    if network.cond_embedding is not None:
+        for i in range(2):
+            fp.cond_kernel[i] = leaf(("cond_embedding", f"Dense_{i}", "kernel"))
+            fp.cond_bias[i] = leaf(("cond_embedding", f"Dense_{i}", "bias"))
     return fp
 
 
 def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None:
     te = network.time_embedding
     d_time = 1 if te is None else te.output_dim
+    if network.cond_embedding is not None:
+        cdims = [cond_dim, *network.cond_embedding.hidden_dims]
+        for i in range(len(cdims) - 1):
+            k = params["cond_embedding"][f"Dense_{i}"]["kernel"]
+            if tuple(k.shape) != (cdims[i], cdims[i + 1]):
+                raise ValueError(f"cond_embedding/Dense_{i}/kernel {tuple(k.shape)}, expected {(cdims[i], cdims[i + 1])}")
+        cond_dim = cdims[-1]
     dims = [x_dim + d_time + cond_dim, *network.predictor.hidden_dims, x_dim]
     pp = params[network.predictor_name]
     for i in range(len(dims) - 1):

@@ -109,8 +109,6 @@ def init_params(network, x_dim: int, cond_dim: int, seed: int = 0, bias_std: flo
     """Parameter tree with the reference's default init (orthogonal(sqrt 2) kernels, zero biases;
     ``bias_std`` > 0 draws N(0, bias_std^2) biases for tests).  Mirrors ``network.init`` in
     Model.create (module/model.py:42) for the inputs (x (1,A), t (1,1), cond (1,C))."""
-    if network.cond_embedding is not None:
-        raise NotImplementedError("cond_embedding MLP: not in the fused path yet")
     pred = network.predictor
     if pred.layer_norm or (pred.dropout and pred.dropout > 0):
         raise NotImplementedError("layer_norm / dropout backbones are outside the fused path")
@@ -123,6 +121,11 @@ def init_params(network, x_dim: int, cond_dim: int, seed: int = 0, bias_std: flo
         p["MLP_0"] = {"Dense_0": _dense(gen, d_time, d_time, bias_std), "Dense_1": _dense(gen, d_time, d_time, bias_std)}
         if isinstance(te, LearnableFourierEmbedding):
             p["time_embedding"] = {"kernel": (0.2 * torch.randn((d_time // 2, 1), generator=gen)).to(torch.float32)}
+    ce = network.cond_embedding
+    if ce is not None:   # MLP(hidden_dims=(128, 128), activation=act), no output layer (dacer.py:263-266)
+        cdims = [cond_dim, *ce.hidden_dims]
+        p["cond_embedding"] = {f"Dense_{i}": _dense(gen, cdims[i], cdims[i + 1], bias_std) for i in range(len(ce.hidden_dims))}
+        cond_dim = cdims[-1]
     dims = [x_dim + d_time + cond_dim, *pred.hidden_dims, x_dim]
     p[network.predictor_name] = {f"Dense_{i}": _dense(gen, dims[i], dims[i + 1], bias_std) for i in range(len(dims) - 1)}
     return tree_to(p, device)

@@ -86,6 +86,9 @@ typedef struct FrlDesc {
   float x_min, x_max;
   int32_t dtype;        /* FRL_DTYPE_* */
   int32_t want_history; /* 1: write xt_hist / eps_hist (ddpm.py:217) */
+  int32_t cond_embed;   /* 1: a cond_embedding MLP(hidden_dims=(128,128), act) (dacer.py:263-266, qvpo.py:204-207)
+                           maps each raw condition row (cond_in_dim) to the cond_dim = 128 features, once per STATE */
+  int32_t cond_in_dim;  /* raw observation width when cond_embed = 1 */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a
@@ -97,6 +100,8 @@ typedef struct FrlParams {
   const float* kernel[FRL_MAX_HIDDEN + 1]; /* params/{noise,vel}_predictor/Dense_i/kernel; i = 0..L     */
   const float* bias[FRL_MAX_HIDDEN + 1];   /* .../Dense_i/bias. Dense_0 kernel is (A + D' + C, H0) with
                                               row order x | time | cond (ddpm.py:92), D' = D or 1      */
+  const float* cond_kernel[2]; /* params/cond_embedding/Dense_{0,1}/kernel (cond_in_dim,128), (128,128); cond_embed only */
+  const float* cond_bias[2];   /* params/cond_embedding/Dense_{0,1}/bias (128,) */
 } FrlParams;
 
 /* Noise-schedule tables, each (T+1,) float32 on the device.
@@ -113,7 +118,8 @@ typedef struct FrlSchedule {
 
 typedef struct FrlFwdBufs {
   const float* xT;    /* (B, A)  start of the chain (x0 for CNF)                          */
-  const float* cond;  /* (n_states, C) un-repeated condition rows, NULL iff cond_dim == 0  */
+  const float* cond;  /* (n_states, C) un-repeated condition rows, NULL iff cond_dim == 0;
+                         (n_states, cond_in_dim) raw observations when desc.cond_embed = 1      */
   const float* noise; /* (T, B, A): noise[j] = the N(0,I) draw of loop iteration j (ddpm.py:206,
                          continuous_ddpm.py:174), drawn by the caller with the reference's key
                          sequence.  NULL for solvers without noise (ddim, euler)              */
@@ -135,10 +141,10 @@ size_t frl_workspace_bytes(const FrlDesc* desc);
 int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
                         void* workspace, size_t workspace_bytes, void* hip_stream);
 
-/* Stage 2: the persistent fused T-step kernel.  Needs a workspace filled by frl_sampler_prepare
+/* Stage 2: (cond_embedding kernel, once per state, when desc.cond_embed) + the persistent fused T-step kernel.  Needs a workspace filled by frl_sampler_prepare
  * for the same desc/params on the same stream (or an earlier, completed one). */
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
-                    const void* workspace, size_t workspace_bytes, void* hip_stream);
+                    void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* prepare + run: the whole of DDPM.sample / ContinuousDDPM.sample / CNF.sample minus RNG. */
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,

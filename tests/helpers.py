@@ -28,18 +28,20 @@ class Case:
     approx_postvar: bool = False
     particles: int = 1
     seed: int = 0
+    cond_embed: bool = False       # cond_embedding MLP(128,128): S is then the RAW obs width
 
     @property
     def spec(self):
         return orc.BackboneSpec(hidden_dims=list(self.hidden), x_dim=self.A, activation=self.act,
                                 time_embedding=self.temb, time_dim=64,
+                                cond_hidden=[128, 128] if self.cond_embed else None,
                                 predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor")
 
 
 def make_inputs(c: Case):
     """numpy float32 inputs + params (Flax layout) for a case; condition is un-repeated (n_states, S)."""
     rng = np.random.default_rng(1000 + c.seed)
-    params = orc.make_params(c.spec, c.S, seed=c.seed)
+    params = orc.make_params(c.spec, c.S, seed=c.seed, cond_in_dim=c.S)
     n_states = c.B // c.particles
     assert n_states * c.particles == c.B
     xT = rng.standard_normal((c.B, c.A)).astype(np.float32)
@@ -76,19 +78,20 @@ def product_model(c: Case, params, device="cuda"):
     elif c.temb == "learnable_fourier":
         te = fh.LearnableFourierEmbedding(output_dim=64)
     mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act)
+    ce = fh.MLP(hidden_dims=[128, 128], activation=c.act) if c.cond_embed else None
     tparams = fh.tree_from_numpy(params, device)
     inputs = (np.ones((1, c.A)), np.zeros((1, 1)), np.ones((1, c.S)) if c.S > 0 else None)
     if c.kind == "ddpm":
-        net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te)
+        net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te, cond_embedding=ce)
         return DDPM.create(net, 0, inputs, x_dim=c.A, steps=c.T, noise_schedule=c.schedule,
                            approx_postvar=c.approx_postvar, clip_sampler=c.clip, x_min=c.x_min, x_max=c.x_max,
                            params=tparams, device=device)
     if c.kind == "cddpm":
-        net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te)
+        net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te, cond_embedding=ce)
         return ContinuousDDPM.create(net, 0, inputs, x_dim=c.A, steps=c.T, noise_schedule=c.schedule,
                                      clip_sampler=c.clip, x_min=c.x_min, x_max=c.x_max, solver=c.solver,
                                      params=tparams, device=device)
-    net = fh.FlowBackbone(vel_predictor=mlp, time_embedding=te)
+    net = fh.FlowBackbone(vel_predictor=mlp, time_embedding=te, cond_embedding=ce)
     return ContinuousNormalizingFlow.create(net, 0, inputs, x_dim=c.A, steps=c.T, clip_sampler=c.clip,
                                             x_min=c.x_min, x_max=c.x_max, params=tparams, device=device)
 

@@ -136,6 +136,18 @@ def test_cddpm_humanoid_wide_operands():
                   schedule="cosine", seed=24))
 
 
+def test_cddpm_dacer_cond_embedding():
+    # cfg4: DACER / QVPO humanoid shape (obs 376 -> cond_embedding 128 -> 128, act 17, 256x3 mish, T=20, cosine,
+    # learnable-Fourier time embedding, clip +-1), particles per state broadcast in-kernel
+    _check(H.Case("cfg4-dacer", "cddpm", A=17, S=376, T=20, B=20 * 16, particles=16, temb="learnable_fourier",
+                  schedule="cosine", cond_embed=True, seed=25))
+
+
+def test_cddpm_qvpo_256x2_cond_embedding_ragged():
+    _check(H.Case("cfg4-qvpo", "cddpm", A=17, S=376, T=20, B=37 * 3, particles=3, hidden=(256, 256), temb="learnable_fourier",
+                  schedule="cosine", cond_embed=True, seed=26))
+
+
 @pytest.mark.parametrize("act", ["gelu_tanh", "tanh", "elu", "silu", "relu"])
 def test_all_activations(act):
     _check(H.Case(f"act-{act}", "ddpm", A=3, S=11, T=5, B=96, hidden=(256, 256), act=act, seed=30))
