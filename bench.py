@@ -30,44 +30,91 @@ import torch
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32)
 
 WORKLOADS = {
-    # name: dict(kind, A, S, T, B, hidden, act, schedule, clip, x_min, x_max)
-    "cfg1": dict(desc="toy2d DDPM (obs 1, act 2, 256x3 mish, linear, T=20, B=4096)",
-                 A=2, S=1, T=20, B=4096, hidden=[256, 256, 256], act="mish", schedule="linear", clip=False,
-                 x_min=-4.0, x_max=4.0),
-    "cfg2": dict(desc="DQL/DAC DDPM hopper (obs 11, act 3, 256x3 mish, vp, T=5, clip +-1, B=262144/GPU)",
-                 A=3, S=11, T=5, B=262144, hidden=[256, 256, 256], act="mish", schedule="vp", clip=True,
-                 x_min=-1.0, x_max=1.0),
+    # BASELINE.json configs[0..3]; B = chains per GPU (n_states * particles)
+    "cfg1": dict(desc="toy2d DDPM (obs 1, act 2, 256x3 mish, linear, T=20, B=4096)", kind="ddpm",
+                 A=2, S=1, T=20, B=4096, particles=1, hidden=[256, 256, 256], act="mish", temb="positional",
+                 schedule="linear", clip=False, x_min=-4.0, x_max=4.0, cond_embed=False),
+    "cfg2": dict(desc="DQL/DAC DDPM hopper (obs 11, act 3, 256x3 mish, vp, T=5, clip +-1, B=262144/GPU)", kind="ddpm",
+                 A=3, S=11, T=5, B=262144, particles=1, hidden=[256, 256, 256], act="mish", temb="positional",
+                 schedule="vp", clip=True, x_min=-1.0, x_max=1.0, cond_embed=False),
+    "cfg3": dict(desc="FQL flow Euler (obs 39, act 8, 512x4 gelu-tanh, raw t, 10 steps, B=1048576/GPU)", kind="cnf",
+                 A=8, S=39, T=10, B=1048576, particles=1, hidden=[512, 512, 512, 512], act="gelu_tanh", temb=None,
+                 schedule=None, clip=False, x_min=None, x_max=None, cond_embed=False),
+    "cfg4": dict(desc="DACER ContinuousDDPM humanoid (obs 376 -> cond-embed 128, act 17, 256x3 mish, Fourier-64, cosine, "
+                      "T=20, clip +-1, 8192 states x 64 particles/GPU)", kind="cddpm",
+                 A=17, S=376, T=20, B=8192 * 64, particles=64, hidden=[256, 256, 256], act="mish", temb="learnable_fourier",
+                 schedule="cosine", clip=True, x_min=-1.0, x_max=1.0, cond_embed=True),
 }
 
 
 def build_model(w, device, seed=0):
     import flowrl_hip as fh
-    from flowrl_hip.flow import DDPM
-    net = fh.DDPMBackbone(noise_predictor=fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"]),
-                          time_embedding=fh.PositionalEmbedding(output_dim=64))
-    params = fh.init_params(net, w["A"], w["S"], seed=seed, bias_std=0.1, device=device)
+    from flowrl_hip.flow import DDPM, ContinuousDDPM, ContinuousNormalizingFlow
+    te = {"positional": fh.PositionalEmbedding(output_dim=64), "learnable_fourier": fh.LearnableFourierEmbedding(output_dim=64),
+          None: None}[w["temb"]]
+    mlp = fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"])
+    ce = fh.MLP(hidden_dims=[128, 128], activation=w["act"]) if w["cond_embed"] else None
     inputs = (np.ones((1, w["A"])), np.zeros((1, 1)), np.ones((1, w["S"])))
-    return DDPM.create(net, 0, inputs, x_dim=w["A"], steps=w["T"], noise_schedule=w["schedule"],
-                       clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], params=params, device=device)
+    if w["kind"] == "cnf":
+        net = fh.FlowBackbone(vel_predictor=mlp, time_embedding=te, cond_embedding=ce)
+        params = fh.init_params(net, w["A"], w["S"], seed=seed, bias_std=0.1, device=device)
+        return ContinuousNormalizingFlow.create(net, 0, inputs, x_dim=w["A"], steps=w["T"], clip_sampler=w["clip"],
+                                                x_min=w["x_min"], x_max=w["x_max"], params=params, device=device)
+    net = fh.DDPMBackbone(noise_predictor=mlp, time_embedding=te, cond_embedding=ce)
+    params = fh.init_params(net, w["A"], w["S"], seed=seed, bias_std=0.1, device=device)
+    if w["kind"] == "ddpm":
+        return DDPM.create(net, 0, inputs, x_dim=w["A"], steps=w["T"], noise_schedule=w["schedule"],
+                           clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], params=params, device=device)
+    return ContinuousDDPM.create(net, 0, inputs, x_dim=w["A"], steps=w["T"], noise_schedule=w["schedule"],
+                                 clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], params=params, device=device)
+
+
+def make_inputs(w, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    B, A, S, T = w["B"], w["A"], w["S"], w["T"]
+    xT = torch.randn((B, A), generator=g, device=device)
+    cond = torch.randn((B // w["particles"], S), generator=g, device=device)     # un-repeated: one row per state
+    noise = torch.randn((T, B, A), generator=g, device=device) if w["kind"] != "cnf" else None
+    return xT, cond, noise
+
+
+def sample(model, w, xT, cond, noise):
+    p = w["particles"] if w["particles"] > 1 else None
+    if w["kind"] == "cnf":
+        return model.sample(None, xT, cond, particles=p)[1]
+    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p)[1]
 
 
 def kernel_only_ms(model, w, xT, cond, noise, iters):
-    """Average duration of the dominant kernel (the fused T-step sampler) alone: prepare once, then
-    `iters` launches of frl_sampler_run bracketed by events on the launch stream."""
+    """Average duration of the dominant kernel (the fused T-step sampler) alone: prepare once, then `iters`
+    launches of frl_sampler_run bracketed by events on the launch stream (for cfg4 this includes the
+    cond-embedding kernel, < 0.1 % of the FLOPs)."""
     from flowrl_hip import _lib, _sampler
+    from flowrl_hip import schedules as sch
     lib = _lib.load()
     dev = xT.device
     keep = []
-    desc = _sampler.build_desc(model.network, kind=_lib.FRL_KIND_DDPM, solver=_lib.FRL_SOLVER_DDPM, steps=w["T"],
-                               n_states=xT.shape[0], particles=1, x_dim=w["A"], cond_dim=w["S"],
-                               clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False)
+    kind = {"ddpm": _lib.FRL_KIND_DDPM, "cddpm": _lib.FRL_KIND_CDDPM, "cnf": _lib.FRL_KIND_CNF}[w["kind"]]
+    desc = _sampler.build_desc(model.network, kind=kind, solver=_lib.FRL_SOLVER_EULER if w["kind"] == "cnf" else _lib.FRL_SOLVER_DDPM,
+                               steps=w["T"], n_states=w["B"] // w["particles"], particles=w["particles"], x_dim=w["A"],
+                               cond_dim=w["S"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False)
     fp = _sampler.build_params(model.network, model.params, dev, keep)
     fs = _lib.FrlSchedule()
-    fs.betas, fs.alphas = model.betas.data_ptr(), model.alphas.data_ptr()
-    fs.alpha_hats, fs.postvars = model.alpha_hats.data_ptr(), model.postvars.data_ptr()
+    if w["kind"] == "ddpm":
+        tabs = dict(betas=model.betas, alphas=model.alphas, alpha_hats=model.alpha_hats, postvars=model.postvars)
+    elif w["kind"] == "cddpm":
+        ts, ah, al, be = sch.continuous_tables(w["T"], model.noise_schedule_func, model.t_diffusion, model.t_schedule_n)
+        tabs = {k: torch.from_numpy(v).to(dev) for k, v in dict(ts=ts, alpha_hats=ah, alphas=al, betas=be).items()}
+    else:
+        tabs = {}
+    for k, v in tabs.items():
+        keep.append(v)
+        setattr(fs, k, v.data_ptr())
     x0 = torch.empty_like(xT)
     bufs = _lib.FrlFwdBufs()
-    bufs.xT, bufs.cond, bufs.noise, bufs.x0 = xT.data_ptr(), cond.data_ptr(), noise.data_ptr(), x0.data_ptr()
+    bufs.xT, bufs.cond, bufs.x0 = xT.data_ptr(), cond.data_ptr(), x0.data_ptr()
+    if noise is not None:
+        bufs.noise = noise.data_ptr()
     need = lib.frl_workspace_bytes(C.byref(desc))
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -96,21 +143,29 @@ def cpu_baseline(w, budget_s=15.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    spec = orc.BackboneSpec(hidden_dims=w["hidden"], x_dim=w["A"], activation=w["act"], time_embedding="positional")
-    params = orc.make_params(spec, w["S"], seed=0)
-    tables = orc.ddpm_tables(w["T"], w["schedule"])
+    spec = orc.BackboneSpec(hidden_dims=w["hidden"], x_dim=w["A"], activation=w["act"], time_embedding=w["temb"],
+                            cond_hidden=[128, 128] if w["cond_embed"] else None,
+                            predictor_name="vel_predictor" if w["kind"] == "cnf" else "noise_predictor")
+    params = orc.make_params(spec, w["S"], seed=0, cond_in_dim=w["S"])
     rng = np.random.default_rng(0)
+    kw = dict(steps=w["T"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"])
 
     def run(Bs):
+        Bs = (Bs // w["particles"]) * w["particles"]
         xT = rng.standard_normal((Bs, w["A"])).astype(np.float32)
-        cond = rng.standard_normal((Bs, w["S"])).astype(np.float32)
+        # the reference materialises obs_repeat (dql.py:145) and runs the whole net per particle
+        cond = np.repeat(rng.standard_normal((Bs // w["particles"], w["S"])).astype(np.float32), w["particles"], axis=0)
         nz = rng.standard_normal((w["T"], Bs, w["A"])).astype(np.float32)
         t0 = time.perf_counter()
-        orc.ddpm_sample(spec, params, tables, xT, cond, nz, steps=w["T"], clip_sampler=w["clip"],
-                        x_min=w["x_min"], x_max=w["x_max"])
+        if w["kind"] == "ddpm":
+            orc.ddpm_sample(spec, params, orc.ddpm_tables(w["T"], w["schedule"]), xT, cond, nz, **kw)
+        elif w["kind"] == "cddpm":
+            orc.continuous_ddpm_sample(spec, params, orc.continuous_tables(w["T"], w["schedule"]), xT, cond, nz, **kw)
+        else:
+            orc.cnf_sample(spec, params, xT, cond, **kw)
         return time.perf_counter() - t0
 
-    probe_B = 4096
+    probe_B = 4096 if w["hidden"][0] <= 256 else 2048
     run(probe_B)                      # warm-up (BLAS threads, page faults)
     t_probe = run(probe_B)
     Bs = int(min(w["B"], max(probe_B, probe_B * budget_s / max(t_probe, 1e-3))))
@@ -159,22 +214,16 @@ def main():
     B, T, A, S = w["B"], w["T"], w["A"], w["S"]
     model = build_model(w, dev)
     if args.kernel_only:
-        g = torch.Generator(device=dev).manual_seed(1234)
-        xT = torch.randn((w["B"], w["A"]), generator=g, device=dev)
-        cond = torch.randn((w["B"], w["S"]), generator=g, device=dev)
-        noise = torch.randn((w["T"], w["B"], w["A"]), generator=g, device=dev)
+        xT, cond, noise = make_inputs(w, dev, 1234)
         k_ms, fa, fe = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
         print(json.dumps({"kernel_ms": k_ms, "act": w["act"], "layers": len(w["hidden"]), "alg_tflops": fa / k_ms / 1e9,
                           "exec_tflops": fe / k_ms / 1e9}))
         return
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    xT = torch.randn((B, A), generator=g, device=dev)
-    cond = torch.randn((B, S), generator=g, device=dev)     # this rank's shard of the states
-    noise = torch.randn((T, B, A), generator=g, device=dev)
+    xT, cond, noise = make_inputs(w, dev, 1234 + rank)       # this rank's shard of the states
     gathered = torch.empty((world * B, A), device=dev) if world > 1 else None
 
     def step():
-        _, x0, _ = model.sample(None, xT, cond, False, "ddpm", noise=noise)
+        x0 = sample(model, w, xT, cond, noise)
         if world > 1 and not args.no_gather:
             dist.all_gather_into_tensor(gathered, x0)
         return x0
@@ -206,7 +255,7 @@ def main():
         k_ms, flops_alg, flops_exec = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": "action samples/sec x T steps (chain-steps/s), fused sampler, 256x3 MLP",
+            "metric": "action samples/sec x T steps (chain-steps/s), fused sampler",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -214,7 +263,7 @@ def main():
                        "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else "all_gather(x0)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "frl_sampler_g32_kernel", "kernel_ms": k_ms,
+                         "kernel": "frl_sampler_rs_kernel", "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_executed_mfma": flops_exec,
                          "achieved_executed": flops_exec / (k_ms * 1e-3) / 1e12},
         }

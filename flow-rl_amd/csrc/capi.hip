@@ -55,7 +55,7 @@ static int validate_desc(const FrlDesc* d) {
   {
     Plan pl;
     plan_from_desc(*d, pl);
-    const bool ok = (pl.H == 256) ? ((pl.AR <= 4 && pl.CK <= 12) || (pl.AR <= 12 && pl.CK <= 64)) : (pl.AR <= 4 && pl.CK <= 12);
+    const bool ok = (pl.TR == 32) ? ((pl.AR <= 4 && pl.CK <= 12) || (pl.AR <= 12 && pl.CK <= 64)) : (pl.AR <= 4 && pl.CK <= 12);
     if (!ok) {
       set_error("x_dim %d / cond_dim %d exceed the compiled operand budgets for hidden width %d "
                 "(256: x_dim <= 24, cond_dim <= 128; 512: x_dim <= 16, cond_dim <= 48)", d->x_dim, d->cond_dim, pl.H);
@@ -185,7 +185,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
-  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H;
+  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;

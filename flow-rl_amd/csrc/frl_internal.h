@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "flowrl_hip.h"
 
@@ -30,6 +31,12 @@ enum Mode : int {
   MODE_CNF_EULER = 4,   // cnf.py:108-110
 };
 
+// FRL_GEO=16 selects the 16x16x4 geometry for 256-wide nets too (A/B measurements)
+inline bool prefer_tr16() {
+  static const bool v = [] { const char* e = getenv("FRL_GEO"); return e != nullptr && e[0] == '1' && e[1] == '6'; }();
+  return v;
+}
+
 // Derived sizes of one call (host + device agree through this one function).
 struct Plan {
   int A, C, D, Dp;      // action dim, cond dim, time_dim, D' (= D or 1) rows of Dense_0 taken by time
@@ -54,7 +61,7 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
   p.H = d.hidden[0];
-  p.TR = (p.H <= 256) ? 32 : 16;
+  p.TR = (p.H <= 256 && !prefer_tr16()) ? 32 : 16;
   p.KS = (p.TR == 32) ? 2 : 4;
   p.NR = (p.TR == 32) ? 16 : 4;
   p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
@@ -91,7 +98,7 @@ struct KArgs {
   const float* bh[FRL_MAX_HIDDEN - 1];
   const float* ws_coef; const float* ws_tb; const float* ws_w0p; const float* ws_wlp; const float* ws_wlq; const float* ws_blp;
   long long B;
-  int particles, A, C, T, L, H, mode, clip;
+  int particles, A, C, T, L, H, TR, mode, clip;
   int w0p_bytes;
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;

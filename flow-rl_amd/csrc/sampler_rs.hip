@@ -430,6 +430,7 @@ static int launch_inst(const KArgs& a, hipStream_t stream) {
 
 template <int ACT>
 int launch_sampler_rs_act(const KArgs& a, hipStream_t stream) {
+  if (a.H == 256 && a.TR == 16 && a.AR <= 4 && a.CK <= 12) return launch_inst<16, 256, ACT, 4, 12>(a, stream);
 #ifndef FRL_RS_SKIP_A
   if (a.H == 256 && a.AR <= 4 && a.CK <= 12) return launch_inst<32, 256, ACT, 4, 12>(a, stream);
 #endif
