@@ -113,6 +113,55 @@ struct PArgs {
   int kind, time_embed;
 };
 
+// ---- backward (chain VJP) -------------------------------------------------------------------------------
+// Workspace of frl_sampler_bwd = the forward tables (Plan) followed by transposed / packed weight images and the
+// per-(wave-tile, step, layer) stash [64 register pairs][64 lanes][2] f32 = 32 KB each:
+//   Hd = act(z_l)   (input of Dense_{l+1}: the X operand of dW_{l+1})
+//   Ad = act'(z_l)  (re-read by the backward sweep)
+//   Gd = dL/dz_l    (the G operand of dW_l)
+struct BwdPlan {
+  Plan f;
+  long long n_wt, n_ts;          // wave tiles (32 chains), tile-steps
+  size_t off_wt[FRL_MAX_HIDDEN - 1];   // transposed hidden kernels WT_l[out][in]
+  size_t off_wlt;                // transposed, row-padded last kernel  [XR][H]
+  size_t off_w0xq;               // per-lane packed image of Dense_0's x rows (A operand of dx = W0x G_0)
+  size_t off_hd, off_ad, off_gd; // stash, n_ts * L * 8192 floats each
+  size_t off_ge;                 // dL/deps per tile-step: [NRX=4 regs][64 lanes]
+  size_t total_floats;
+};
+
+inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
+  plan_from_desc(d, b.f);
+  const Plan& p = b.f;
+  b.n_wt = (p.B + 31) / 32;
+  b.n_ts = b.n_wt * p.T;
+  size_t o = p.total_floats;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+  for (int l = 1; l < p.L; ++l) b.off_wt[l - 1] = take((size_t)p.H * p.H);
+  b.off_wlt = take((size_t)p.XR * p.H);
+  b.off_w0xq = take((size_t)p.H * 64);
+  b.off_hd = take((size_t)b.n_ts * p.L * 8192);
+  b.off_ad = take((size_t)b.n_ts * p.L * 8192);
+  b.off_gd = take((size_t)b.n_ts * p.L * 8192);
+  b.off_ge = take((size_t)b.n_ts * 256);
+  b.total_floats = o;
+  return 0;
+}
+
+struct BArgs {
+  KArgs k;                        // forward arguments (xT unused; k.noise unused)
+  const float* xt_hist; const float* g_x0; float* g_xT;
+  const float* wt[FRL_MAX_HIDDEN - 1];  // transposed hidden kernels
+  const float* ws_wlt; const float* ws_w0xq;
+  float* hd; float* ad; float* gd; float* ge;
+  float* grad_kernel[FRL_MAX_HIDDEN + 1]; float* grad_bias[FRL_MAX_HIDDEN + 1]; float* grad_tb;
+  int Dp;                         // time rows of Dense_0 (skipped by the dW_0 scatter)
+  long long n_ts;
+};
+
+int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
+int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, hipStream_t stream);
+
 void set_error(const char* fmt, ...);
 
 // launchers implemented in the .hip files

@@ -1,0 +1,627 @@
+// Chain VJP of the fused sampler (DQL-style actor update: flowrl/agent/offline/dql.py:93-123 runs jax.grad
+// through the T unrolled steps of DDPM.sample, flowrl/flow/ddpm.py:186-219; model.py:78-86).
+//
+// Three kernels, exact-f32 MFMA, 256-wide predictor, the transposed [feature x chain] register layout of
+// sampler_rs.hip:
+//
+//   frl_bwd_prepare_kernel   transposed hidden kernels WT_l[out][in], row-padded W_L^T, packed Dense_0 x rows
+//   frl_bwd_sweep_kernel     per wave-tile of 32 chains, steps j = T-1 .. 0:
+//                              recompute the forward of step j from the stashed x_j (only xt_hist was kept),
+//                              writing h_l = act(z_l) and a_l = act'(z_l) of every layer to the stash;
+//                              VJP of the DDPM / DDIM / Euler update -> dL/deps, direct dL/dx_j;
+//                              dL/dh_{l-1} = W_l dL/dz_l layer by layer — the forward's hidden-layer code with
+//                              the transposed kernel, dL/dz_l = dL/dh_l * a_l applied lazily as the B operand
+//                              and written to the stash; dL/dx_j += W0[x rows] dL/dz_0
+//   frl_bwd_dw_kernel        dW_l = sum over chains and steps of h_{l-1} (x) dL/dz_l: a split-K GEMM whose K is
+//                              the 1.3 M chain-steps — each CU owns a K range and the whole 256 x 256 tile in
+//                              accumulators (256 per lane), operands transposed through LDS, one float-atomic
+//                              flush per layer; bias grads = column sums taken from the same LDS tiles.
+//
+// Weight gradients contract over CHAINS (the lane axis of the sweep), so they cannot be accumulated inside the
+// sweep without 64 K accumulators per wave: the stash (3 x 32 KB per tile-step and layer) is what links the two.
+#include "frl_device.h"
+
+namespace frl {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 ld2(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void st2(f32x2 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+}
+
+// activation and its derivative for a register pair (shared exp / rcp)
+template <int ACT>
+__device__ __forceinline__ void act_grad2(f32x2 z, f32x2& h, f32x2& d) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  if constexpr (ACT == FRL_ACT_MISH) {
+    // h = z n / (n + 2), n = e (e + 2);  h' = n r + 4 z e (e + 1) r^2,  r = 1 / (n + 2)
+    f32x2 c = {__builtin_amdgcn_fmed3f(z[0], -88.0f, 20.0f), __builtin_amdgcn_fmed3f(z[1], -88.0f, 20.0f)};
+    c = c * LOG2E;
+    const f32x2 e = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
+    const f32x2 u = e + 2.0f;
+    const f32x2 n = e * u;
+    const f32x2 dd = e * u + 2.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+    const f32x2 nr = n * r;
+    const f32x2 q = e * (e + 1.0f);
+    const f32x2 zr = z * r;
+    h = z * nr;
+    d = (q * 4.0f) * (zr * r) + nr;
+  } else if constexpr (ACT == FRL_ACT_SILU) {
+    f32x2 c = {__builtin_amdgcn_fmed3f(-z[0], -88.0f, 80.0f), __builtin_amdgcn_fmed3f(-z[1], -88.0f, 80.0f)};
+    c = c * LOG2E;
+    const f32x2 dd = f32x2{__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])} + 1.0f;
+    const f32x2 s = {__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+    h = z * s;
+    d = h * (1.0f - s) + s;
+  } else {  // RELU
+    h = f32x2{fmaxf(z[0], 0.0f), fmaxf(z[1], 0.0f)};
+    d = f32x2{z[0] > 0.0f ? 1.0f : 0.0f, z[1] > 0.0f ? 1.0f : 0.0f};
+  }
+}
+
+// ---- preparation: transposed / packed weight images -------------------------------------------------------
+struct PBArgs {
+  const float* kernel[FRL_MAX_HIDDEN + 1];
+  float* wt[FRL_MAX_HIDDEN - 1];
+  float* wlt; float* w0xq;
+  int H, L, A, XR;
+};
+
+__global__ void __launch_bounds__(256) frl_bwd_prepare_kernel(const PBArgs p) {
+  const int H = p.H;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gsz = (long long)gridDim.x * blockDim.x;
+  for (int l = 1; l < p.L; ++l) {               // WT_l[o][i] = W_l[i][o]
+    const float* W = p.kernel[l];
+    float* WT = p.wt[l - 1];
+    for (long long idx = gid; idx < (long long)H * H; idx += gsz) {
+      const int o = (int)(idx / H), i = (int)(idx - (long long)o * H);
+      WT[idx] = W[(size_t)i * H + o];
+    }
+  }
+  const float* WL = p.kernel[p.L];               // (H, A)  ->  wlt[a][f] = WL[f][a], zero rows beyond A
+  for (long long idx = gid; idx < (long long)p.XR * H; idx += gsz) {
+    const int a = (int)(idx / H), f = (int)(idx - (long long)a * H);
+    p.wlt[idx] = (a < p.A) ? WL[(size_t)f * p.A + a] : 0.0f;
+  }
+  // Dense_0 x rows as the A operand of dx[a] = sum_f W0[a][f] G_0[f]: same per-lane packing as the forward's
+  // Dense_L image (load q = k-steps 4q..4q+3; lane (i, s) of k-step (block, r) holds feature
+  // 128 g + j + 4 (ROWR(r) + 4 s), output row i = a)
+  const float* W0 = p.kernel[0];
+  for (long long idx = gid; idx < (long long)H * 64; idx += gsz) {
+    const int q = (int)(idx >> 8), lane = (int)(idx >> 2) & 63, e = (int)idx & 3;
+    const int k = 4 * q + e, blk = k / 16, r = k - blk * 16;
+    const int i = lane & 31, sl = lane >> 5;
+    const int kf = 128 * (blk >> 2) + (blk & 3) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * sl);
+    p.w0xq[idx] = (i < p.A) ? W0[(size_t)i * H + kf] : 0.0f;
+  }
+}
+
+int launch_prepare_bwd(const FrlParams& prm, const BwdPlan& bp, float* ws, hipStream_t stream) {
+  PBArgs p;
+  for (int l = 0; l <= bp.f.L; ++l) p.kernel[l] = prm.kernel[l];
+  for (int l = 1; l < bp.f.L; ++l) p.wt[l - 1] = ws + bp.off_wt[l - 1];
+  p.wlt = ws + bp.off_wlt; p.w0xq = ws + bp.off_w0xq;
+  p.H = bp.f.H; p.L = bp.f.L; p.A = bp.f.A; p.XR = bp.f.XR;
+  hipLaunchKernelGGL(frl_bwd_prepare_kernel, dim3(256), dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("bwd prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+// ---- the sweep ---------------------------------------------------------------------------------------------
+template <int ACT, int NRX, int CKMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+frl_bwd_sweep_kernel(const BArgs b) {
+  typedef Geo<32> G;
+  typedef f32x16 acc_t;
+  constexpr int TR = 32, H = 256, KS = 2, NR = 16, RING = 4;
+  constexpr int NB = H / TR, NG = NB / 4, GW = 4 * TR, NK = NB * NR, ROWB = H * 4, RINGL = 8, NLD = NK / 4;
+  constexpr int N0 = NRX + CKMAX;
+  const KArgs& a = b.k;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int li = lane % TR, ls = lane / TR;
+
+  float* s_tb = (float*)smem;
+  float* s_bh = s_tb + a.T * H;
+  float* s_bl = s_bh + (a.L - 1) * H;
+  float* s_coef = s_bl + LAST_PAD;
+  for (int idx = tid; idx < a.T * H; idx += blockDim.x) s_tb[idx] = a.ws_tb[idx];
+  for (int l = 1; l < a.L; ++l) {
+    const float* bp = pick_ptr_rs(a.bh, l - 1);
+    for (int idx = tid; idx < H; idx += blockDim.x) s_bh[(l - 1) * H + idx] = bp[idx];
+  }
+  if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
+  for (int idx = tid; idx < a.T * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
+  __syncthreads();
+
+  const unsigned voff_h = ls * (16 * ROWB) + li * 16;
+  const unsigned voff_x = ls * (4 * ROWB) + li * 16;
+  const unsigned voff_c = ls * ROWB + li * 16;
+  const unsigned voff_l = lane * 16;
+  const unsigned voff_d = lane * 8;                       // stash rows: [pair][lane][2]
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_w0p, 0, a.w0p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_wlq, 0, NK * 64 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rslt = __builtin_amdgcn_make_buffer_rsrc((void*)b.ws_wlt, 0, a.XR * ROWB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsxq = __builtin_amdgcn_make_buffer_rsrc((void*)b.ws_w0xq, 0, NK * 64 * 4, 0x00020000);
+
+  auto bias_init = [&](acc_t (&Q)[NB], const float* sb) {
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      sfor<NR>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const f32x4 bv = *(const f32x4*)(sb + g * GW + 4 * (G::rowr(r) + 4 * ls));
+        sfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; Q[g * 4 + j][r] = bv[j]; });
+      });
+    });
+  };
+  auto zero_init = [&](acc_t (&Q)[NB]) {
+    sfor<NB>([&](auto BI) { constexpr int bb = decltype(BI)::value; sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; Q[bb][r] = 0.0f; }); });
+  };
+
+  f32x4 ring[RING][NG];
+  auto hload = [&](__amdgpu_buffer_rsrc_t rs, auto KI) {
+    constexpr int k = decltype(KI)::value % NK;
+    constexpr int bb = k / NR, r = k % NR;
+    constexpr int soff = (GW * (bb >> 2) + (bb & 3) + 4 * G::rowr(r)) * ROWB;
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      ring[k % RING][g] = ldw(rs, voff_h + g * (GW * 4), soff);
+    });
+  };
+  f32x4 r0[RING][NG];
+  auto live = [&](int n) { return n < NRX ? n < a.AR : (n - NRX) < a.CK; };
+  auto l0load = [&](auto NI) {
+    constexpr int n = decltype(NI)::value;
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      if constexpr (n < NRX) r0[n % RING][g] = ldw(rs0, voff_x + g * (GW * 4), G::rowr(n) * ROWB);
+      else r0[n % RING][g] = ldw(rs0, voff_c + g * (GW * 4), (a.XR + KS * (n - NRX)) * ROWB);
+    });
+  };
+
+  acc_t P[NB], Q[NB];
+  const long long n_wt = (a.B + TR - 1) / TR;
+
+  for (long long wt = (long long)blockIdx.x * nw + wave; wt < n_wt; wt += (long long)gridDim.x * nw) {
+    const long long chain = wt * TR + li;
+    const bool valid = chain < a.B;
+    const long long state = (a.particles == 1) ? chain : chain / a.particles;
+
+    float cb[CKMAX];
+    sfor<CKMAX>([&](auto CI) {
+      constexpr int c = decltype(CI)::value;
+      const int k = KS * c + ls;
+      cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
+    });
+    float gx[NRX];      // dL/dx_{j+1}, same register layout as the chain state
+    sfor<NRX>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      const int ai = G::rowr(r) + 4 * ls;
+      gx[r] = (valid && ai < a.A) ? b.g_x0[chain * a.A + ai] : 0.0f;
+    });
+
+    for (int jj = 0; jj < a.T; ++jj) {
+      const int j = a.T - 1 - jj;
+      const long long ts = wt * a.T + j;
+      const size_t srow = (size_t)ts * a.L * 8192;          // floats; each layer = 8192 floats = 64 pair rows x 512 B
+      const __amdgpu_buffer_rsrc_t rs_hd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.hd + srow), 0, a.L * 32768, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 32768, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_gd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.gd + srow), 0, a.L * 32768, 0x00020000);
+
+      float xs[NRX];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        xs[r] = (valid && ai < a.A) ? b.xt_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+      });
+
+      // ================= forward of step j, recomputed =====================================================
+      sfor<RING - 1>([&](auto NI) { l0load(NI); });
+      bias_init(P, s_tb + j * H);
+      sfor<N0>([&](auto NI) {
+        constexpr int n = decltype(NI)::value;
+        if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});
+        if (live(n)) {
+          float bop;
+          if constexpr (n < NRX) bop = xs[n]; else bop = cb[n - NRX];
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const f32x4 aw = r0[n % RING][g];
+            sfor<4>([&](auto JI) { constexpr int q = decltype(JI)::value; P[g * 4 + q] = G::mfma(aw[q], bop, P[g * 4 + q]); });
+          });
+        }
+      });
+
+      // hidden Dense_l: consumes h_{l-1} = act(z_{l-1}) pair by pair, stashing h and act'
+      for (int l = 1; l < a.L; ++l) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
+        sfor<RING - 1>([&](auto KI) { hload(rs, KI); });
+        bias_init(Q, s_bh + (l - 1) * H);
+        const int drow = (l - 1) * 32768;
+        float bop, bn1, bn2 = 0.0f;
+        {
+          f32x2 h, d;
+          act_grad2<ACT>(f32x2{P[0][0], P[0][1]}, h, d);
+          st2(h, rs_hd, voff_d, drow); st2(d, rs_ad, voff_d, drow);
+          bop = h[0]; bn1 = h[1];
+        }
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
+          if constexpr ((k & 1) == 1 && k + 2 < NK) {
+            f32x2 h, d;
+            act_grad2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]}, h, d);
+            st2(h, rs_hd, voff_d, drow + ((k + 1) / 2) * 512); st2(d, rs_ad, voff_d, drow + ((k + 1) / 2) * 512);
+            bn1 = h[0]; bn2 = h[1];
+          }
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const f32x4 aw = ring[k % RING][g];
+            sfor<4>([&](auto JI) { constexpr int q = decltype(JI)::value; Q[g * 4 + q] = G::mfma(aw[q], bop, Q[g * 4 + q]); });
+          });
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bop = bn1; bn1 = bn2;
+        });
+        sfor<NB>([&](auto BI) { constexpr int bb = decltype(BI)::value; P[bb] = Q[bb]; });
+      }
+
+      // Dense_L -> eps
+      acc_t O;
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[G::rowr(r) + 4 * ls]; });
+      {
+        f32x4 rl[RINGL];
+        sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
+        const int drow = (a.L - 1) * 32768;
+        float bop, bn1, bn2 = 0.0f;
+        {
+          f32x2 h, d;
+          act_grad2<ACT>(f32x2{P[0][0], P[0][1]}, h, d);
+          st2(h, rs_hd, voff_d, drow); st2(d, rs_ad, voff_d, drow);
+          bop = h[0]; bn1 = h[1];
+        }
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
+            rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsl, voff_l, (k / 4 + RINGL - 1) * 1024);
+          if constexpr ((k & 1) == 1 && k + 2 < NK) {
+            f32x2 h, d;
+            act_grad2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]}, h, d);
+            st2(h, rs_hd, voff_d, drow + ((k + 1) / 2) * 512); st2(d, rs_ad, voff_d, drow + ((k + 1) / 2) * 512);
+            bn1 = h[0]; bn2 = h[1];
+          }
+          O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
+          bop = bn1; bn1 = bn2;
+        });
+      }
+
+      // ================= VJP of the update: dL/deps and the direct part of dL/dx_j ============================
+      const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
+      const float c2 = s_coef[j * COEF_STRIDE + 2], c3 = s_coef[j * COEF_STRIDE + 3];
+      const float c4 = s_coef[j * COEF_STRIDE + 4];
+      float ge[NRX], gxd[NRX];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const float eps = O[r], xt = xs[r], gn = gx[r];
+        float g_e, g_x;
+        if (a.mode == MODE_DDPM_DDPM) {
+          const float x0h = c0 * (xt - c1 * eps);
+          const float m = (!a.clip || (x0h >= a.x_min && x0h <= a.x_max)) ? 1.0f : 0.0f;
+          const float g0 = c2 * c3 * gn * m;
+          g_e = -c0 * c1 * g0; g_x = c2 * c4 * gn + c0 * g0;
+        } else if (a.mode == MODE_DDPM_DDIM) {
+          const float xn = c0 * (xt - c1 * eps) + c2 * eps;
+          const float m = (!a.clip || (xn >= a.x_min && xn <= a.x_max)) ? 1.0f : 0.0f;
+          const float gp = gn * m;
+          g_e = gp * (c2 - c0 * c1); g_x = c0 * gp;
+        } else if (a.mode == MODE_CDDPM_DDPM || a.mode == MODE_CDDPM_DDIM) {
+          const float x0h = (xt - c1 * eps) / c0;
+          const float m = (!a.clip || (x0h >= a.x_min && x0h <= a.x_max)) ? 1.0f : 0.0f;
+          const float g0 = c2 * gn * m;
+          if (a.mode == MODE_CDDPM_DDPM) { g_e = -(c1 / c0) * g0; g_x = c3 * gn + g0 / c0; }
+          else { g_e = -(c1 / c0) * g0 + c3 * gn; g_x = g0 / c0; }
+        } else {
+          const float xn = xt + eps / c0;
+          const float m = (!a.clip || (xn >= a.x_min && xn <= a.x_max)) ? 1.0f : 0.0f;
+          g_e = gn * m / c0; g_x = gn * m;
+        }
+        const int ai = G::rowr(r) + 4 * ls;
+        const bool in = valid && ai < a.A;
+        ge[r] = in ? g_e : 0.0f;
+        gxd[r] = in ? g_x : 0.0f;
+        b.ge[(size_t)ts * 256 + r * 64 + lane] = ge[r];
+      });
+
+      // ================= backward through the net ==================================================================
+      // dL/dh_{L-1} = W_L dL/deps  (k-steps over the action rows, like Dense_0's x part, kernel W_L^T)
+      zero_init(P);
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        if (r < a.AR) {
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const f32x4 aw = ldw(rslt, voff_x + g * (GW * 4), G::rowr(r) * ROWB);
+            sfor<4>([&](auto JI) { constexpr int q = decltype(JI)::value; P[g * 4 + q] = G::mfma(aw[q], ge[r], P[g * 4 + q]); });
+          });
+        }
+      });
+      // hidden layers, downwards: dL/dh_{l-1} = W_l (dL/dh_l * act'(z_l))
+      for (int l = a.L - 1; l >= 1; --l) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(b.wt, l - 1), 0, H * ROWB, 0x00020000);
+        sfor<RING - 1>([&](auto KI) { hload(rs, KI); });
+        zero_init(Q);
+        const int drow = l * 32768;
+        f32x2 ar[4];
+        sfor<3>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, drow + q * 512); });
+        float bop, bn1, bn2 = 0.0f;
+        {
+          ar[3] = ld2(rs_ad, voff_d, drow + 3 * 512);
+          const f32x2 gz = f32x2{P[0][0], P[0][1]} * ar[0];
+          st2(gz, rs_gd, voff_d, drow);
+          bop = gz[0]; bn1 = gz[1];
+        }
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
+          if constexpr ((k & 1) == 1 && k + 2 < NK) {
+            constexpr int rho = (k + 1) / 2;
+            if constexpr (rho + 3 < NK / 2) ar[(rho + 3) % 4] = ld2(rs_ad, voff_d, drow + (rho + 3) * 512);
+            const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % 4];
+            st2(gz, rs_gd, voff_d, drow + rho * 512);
+            bn1 = gz[0]; bn2 = gz[1];
+          }
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const f32x4 aw = ring[k % RING][g];
+            sfor<4>([&](auto JI) { constexpr int q = decltype(JI)::value; Q[g * 4 + q] = G::mfma(aw[q], bop, Q[g * 4 + q]); });
+          });
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bop = bn1; bn1 = bn2;
+        });
+        sfor<NB>([&](auto BI) { constexpr int bb = decltype(BI)::value; P[bb] = Q[bb]; });
+      }
+      // dL/dx_j (net part) = W0[x rows] (dL/dh_0 * act'(z_0)); also stashes dL/dz_0
+      acc_t OX;
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; OX[r] = 0.0f; });
+      {
+        f32x4 rl[RINGL];
+        sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsxq, voff_l, q * 1024); });
+        f32x2 ar[4];
+        sfor<4>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, q * 512); });
+        float bop, bn1, bn2 = 0.0f;
+        {
+          const f32x2 gz = f32x2{P[0][0], P[0][1]} * ar[0];
+          st2(gz, rs_gd, voff_d, 0);
+          bop = gz[0]; bn1 = gz[1];
+        }
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
+            rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsxq, voff_l, (k / 4 + RINGL - 1) * 1024);
+          if constexpr ((k & 1) == 1 && k + 2 < NK) {
+            constexpr int rho = (k + 1) / 2;
+            if constexpr (rho + 3 < NK / 2) ar[(rho + 3) % 4] = ld2(rs_ad, voff_d, (rho + 3) * 512);
+            const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % 4];
+            st2(gz, rs_gd, voff_d, rho * 512);
+            bn1 = gz[0]; bn2 = gz[1];
+          }
+          OX = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, OX);
+          bop = bn1; bn1 = bn2;
+        });
+      }
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        gx[r] = (valid && ai < a.A) ? gxd[r] + OX[r] : 0.0f;
+      });
+    }
+    if (b.g_xT != nullptr) {
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        if (valid && ai < a.A) b.g_xT[chain * a.A + ai] = gx[r];
+      });
+    }
+  }
+}
+
+// ---- weight gradients: split-K GEMM over the stash -------------------------------------------------------------
+// One workgroup (4 waves, 2 x 2) owns tile-steps ts = blockIdx, blockIdx + grid, ... and, layer after layer, the whole
+// dW_l tile in accumulators.  Per tile-step the two operands (X = inputs of the layer, G = dL/dz of the layer, both
+// [features][32 chains]) are staged transposed into LDS ([feature][33]: conflict-free for the write and for the
+// feature-on-lane read) and contracted over the 32 chains with 16 k-steps of v_mfma_f32_32x32x2_f32.
+__device__ __forceinline__ int stash_feature(int row2, int e, int lane) {
+  // stash element (pair row rho, lane, e): k = 2 rho + e = block*16 + r; feature = 128 g + j + 4 (ROWR(r) + 4 s)
+  const int k = 2 * row2 + e, blk = k >> 4, r = k & 15;
+  return 128 * (blk >> 2) + (blk & 3) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+frl_bwd_dw_kernel(const BArgs b) {
+  constexpr int H = 256, LDP = 33;
+  const KArgs& a = b.k;
+  extern __shared__ __attribute__((aligned(16))) float smem_dw[];
+  float* sX = smem_dw;
+  float* sG = smem_dw + H * LDP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;       // 8 waves: 4 (X blocks 2 wm, 2 wm + 1) x 2 (G blocks 4 wn .. 4 wn + 3)
+  const int A = a.A, C = a.C, T = a.T, L = a.L;
+  const long long n_ts = b.n_ts;
+
+  for (int lam = 0; lam <= L; ++lam) {
+    // operand shapes of this layer: X rows (in-features) / G rows (out-features), in 32-row blocks
+    const int xb = (lam == 0) ? 1 : 8, gb = (lam == L) ? 1 : 8;
+    f32x16 acc[2][4];
+    sfor<2>([&](auto MI) { sfor<4>([&](auto NI) { sfor<16>([&](auto RI) {
+      acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
+    float bsum = 0.0f;                                   // column sum of G for feature `tid` (bias gradient)
+
+    for (long long ts = blockIdx.x; ts < n_ts; ts += gridDim.x) {
+      const long long wt = ts / T;
+      const int j = (int)(ts - wt * T);
+      const size_t srow = (size_t)ts * L * 8192;
+      __syncthreads();                                   // previous tile-step's readers are done with the LDS tiles
+      // ---- stage X ----
+      if (lam == 0) {
+        // rows [0, A): x_j ; [A, A+C): cond ; rest zero.  One chain per (row, lane&31)
+        for (int idx = tid; idx < 32 * 32; idx += 512) {
+          const int row = idx >> 5, c = idx & 31;
+          const long long chain = wt * 32 + c;
+          float v = 0.0f;
+          if (chain < a.B) {
+            if (row < A) v = b.xt_hist[((long long)j * a.B + chain) * A + row];
+            else if (row < A + C) v = a.cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
+          }
+          sX[row * LDP + c] = v;
+        }
+      } else {
+        const float* src = b.hd + srow + (size_t)(lam - 1) * 8192;
+        for (int row2 = wave; row2 < 64; row2 += 8) {
+          const f32x2 v = *(const f32x2*)(src + ((size_t)row2 * 64 + lane) * 2);
+          sX[stash_feature(row2, 0, lane) * LDP + li] = v[0];
+          sX[stash_feature(row2, 1, lane) * LDP + li] = v[1];
+        }
+      }
+      // ---- stage G ----
+      if (lam == L) {
+        // dL/deps: [4 regs][64 lanes], action row = ROWR(r) + 4 s
+        for (int idx = tid; idx < 32 * 32; idx += 512) sG[(idx >> 5) * LDP + (idx & 31)] = 0.0f;
+        __syncthreads();
+        if (wave < 4) {
+          const int r = wave;                            // 4 registers <-> waves 0..3
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          sG[row * LDP + li] = b.ge[(size_t)ts * 256 + r * 64 + lane];
+        }
+      } else {
+        const float* src = b.gd + srow + (size_t)lam * 8192;
+        for (int row2 = wave; row2 < 64; row2 += 8) {
+          const f32x2 v = *(const f32x2*)(src + ((size_t)row2 * 64 + lane) * 2);
+          sG[stash_feature(row2, 0, lane) * LDP + li] = v[0];
+          sG[stash_feature(row2, 1, lane) * LDP + li] = v[1];
+        }
+      }
+      __syncthreads();
+      // ---- bias gradient: column sums of G (per-step table for Dense_0: the time branch needs dL/dtb[j]) ----
+      if (tid < gb * 32) {
+        float s = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) s += sG[tid * LDP + c];
+        if (lam == 0) atomicAdd(&b.grad_tb[j * H + tid], s);
+        else bsum += s;
+      }
+      // ---- contract over the 32 chains ----
+      // wave (wm, wn): X blocks mb = 4 wm + m (or just block 0), G blocks nb = 4 wn + n; skip blocks that do not exist
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        float av[2], bv[4];
+        sfor<2>([&](auto MI) {
+          constexpr int m = decltype(MI)::value;
+          const int mb = (xb == 1) ? 0 : 2 * wm + m;
+          av[m] = sX[(32 * mb + li) * LDP + 2 * kk + lh];
+        });
+        sfor<4>([&](auto NI) {
+          constexpr int n = decltype(NI)::value;
+          const int nb = (gb == 1) ? 0 : 4 * wn + n;
+          bv[n] = sG[(32 * nb + li) * LDP + 2 * kk + lh];
+        });
+        sfor<2>([&](auto MI) {
+          constexpr int m = decltype(MI)::value;
+          if (xb == 8 || (m == 0 && wm == 0)) {
+            sfor<4>([&](auto NI) {
+              constexpr int n = decltype(NI)::value;
+              if (gb == 8 || (n == 0 && wn == 0))
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+            });
+          }
+        });
+      }
+    }
+
+    // ---- flush: dW_l[in][out] += acc (float atomics, two 128-B row segments per instruction) ----
+    float* gk = b.grad_kernel[lam];
+    const int ncol = (lam == L) ? A : H;                  // row length of this layer's kernel
+    sfor<2>([&](auto MI) {
+      constexpr int m = decltype(MI)::value;
+      if (xb == 8 || (m == 0 && wm == 0)) {
+        sfor<4>([&](auto NI) {
+          constexpr int n = decltype(NI)::value;
+          if (gb == 8 || (n == 0 && wn == 0)) {
+            const int mb = (xb == 1) ? 0 : 2 * wm + m, nb = (gb == 1) ? 0 : 4 * wn + n;
+            sfor<16>([&](auto RI) {
+              constexpr int r = decltype(RI)::value;
+              int in = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              const int out = 32 * nb + li;
+              bool ok = out < ncol;
+              if (lam == 0) {                              // staged rows: x | cond  ->  kernel rows x | (time) | cond
+                ok = ok && in < A + C;
+                if (in >= A) in += b.Dp;
+              }
+              if (ok) atomicAdd(&gk[(size_t)in * ncol + out], acc[m][n][r]);
+            });
+          }
+        });
+      }
+    });
+    if (lam > 0 && tid < gb * 32 && tid < ncol) atomicAdd(&b.grad_bias[lam][tid], bsum);
+  }
+}
+
+// ---- launcher ---------------------------------------------------------------------------------------------------
+template <int ACT>
+static int launch_sweep(const BArgs& b, int grid, int block, size_t lds, hipStream_t stream) {
+  auto kern = frl_bwd_sweep_kernel<ACT, 4, 12>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, b);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("bwd sweep launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
+  const KArgs& a = b.k;
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+  const long long n_wt = (a.B + 31) / 32;
+  long long per_cu = (n_wt + ncu - 1) / ncu;
+  int nw = (int)(per_cu < 1 ? 1 : (per_cu > MAX_WAVES ? MAX_WAVES : per_cu));
+  if (nw == 3) nw = 4;
+  const long long nwg = (n_wt + nw - 1) / nw;
+  const int grid = (int)(nwg < ncu ? nwg : ncu);
+  const size_t lds = sizeof(float) * ((size_t)a.T * 256 + (size_t)(a.L - 1) * 256 + LAST_PAD + (size_t)a.T * COEF_STRIDE);
+  if (lds > 160 * 1024) { set_error("bwd: steps=%d needs %zu B of LDS", a.T, lds); return FRL_EUNSUPPORTED; }
+  int rc;
+  switch (d.act) {
+    case FRL_ACT_MISH: rc = launch_sweep<FRL_ACT_MISH>(b, grid, 64 * nw, lds, stream); break;
+    case FRL_ACT_SILU: rc = launch_sweep<FRL_ACT_SILU>(b, grid, 64 * nw, lds, stream); break;
+    case FRL_ACT_RELU: rc = launch_sweep<FRL_ACT_RELU>(b, grid, 64 * nw, lds, stream); break;
+    default: set_error("bwd: activation %d has no VJP kernel (mish / silu / relu)", d.act); return FRL_EUNSUPPORTED;
+  }
+  if (rc != FRL_OK) return rc;
+  const long long g2 = b.n_ts < ncu ? b.n_ts : ncu;
+  const size_t lds2 = sizeof(float) * 2 * 256 * 33;
+  hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  hipLaunchKernelGGL(frl_bwd_dw_kernel, dim3((int)g2), dim3(512), lds2, stream, b);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+}  // namespace frl

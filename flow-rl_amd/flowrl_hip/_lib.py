@@ -50,6 +50,11 @@ class FrlFwdBufs(C.Structure):
     _fields_ = [("xT", _fp), ("cond", _fp), ("noise", _fp), ("x0", _fp), ("xt_hist", _fp), ("eps_hist", _fp)]
 
 
+class FrlBwdBufs(C.Structure):
+    _fields_ = [("xt_hist", _fp), ("cond", _fp), ("g_x0", _fp), ("g_xT", _fp),
+                ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_tb", _fp)]
+
+
 class FlowRLHipError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libflowrl_hip error {code}: {msg}")
@@ -75,6 +80,9 @@ EXPORTS = {
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_sampler_fwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule),
                                   C.POINTER(FrlFwdBufs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
+    "frl_sampler_bwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule), C.POINTER(FrlBwdBufs),
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_selftest_mfma32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

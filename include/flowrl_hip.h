@@ -150,6 +150,28 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
                     const FrlFwdBufs* bufs, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* ---- chain VJP (DQL-style backprop through the sampler: dql.py:93-123 -> jax.grad through ddpm.py:186-219) ----
+ * Given the forward's history xt_hist (want_history = 1) and the cotangent g_x0 = dL/dx0, computes dL/d(params) of the
+ * predictor MLP and dL/dxT.  The batch-invariant time branch is differentiated by the caller from grad_tb
+ * (dL/d(tb), tb[j] = bias_0 + tfeat[j] @ kernel_0[A:A+D']): its gradients are O(T * D^2) work.
+ * This build: DDPM / ContinuousDDPM / CNF update rules, 256-wide predictor, mish / silu / relu, x_dim <= 8,
+ * x_dim + cond_dim <= 32, no cond_embedding; everything else returns FRL_EUNSUPPORTED. */
+typedef struct FrlBwdBufs {
+  const float* xt_hist; /* (T, B, A) history[0] of the forward call                                     */
+  const float* cond;    /* (n_states, C) as in the forward call                                         */
+  const float* g_x0;    /* (B, A) cotangent of x0                                                        */
+  float* g_xT;          /* (B, A) or NULL: dL/dxT                                                        */
+  float* grad_kernel[FRL_MAX_HIDDEN + 1]; /* dL/d Dense_i kernel, shapes of FrlParams.kernel; OVERWRITTEN.
+                                             Rows [A, A+D') of Dense_0 (time rows) are left zero: see grad_tb */
+  float* grad_bias[FRL_MAX_HIDDEN + 1];   /* dL/d Dense_i bias for i >= 1; bias_0 comes from grad_tb (sum over steps) */
+  float* grad_tb;       /* (T, H) dL/d(tb)                                                                */
+} FrlBwdBufs;
+
+size_t frl_bwd_workspace_bytes(const FrlDesc* desc);
+
+int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlBwdBufs* bufs,
+                    void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Algorithmic FLOPs of one call, SURVEY.md section 8(d): 2*B*T*(K0*H + sum H_l*H_{l+1} + H*A) with
  * the reference's full K0 = A + D' + C; `executed` (may be NULL) receives the MFMA FLOPs the kernel
  * really issues (time slice hoisted, edge layers zero-padded). */

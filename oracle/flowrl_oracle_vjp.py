@@ -1,0 +1,159 @@
+"""CPU oracle for the backprop-through-chain VJP (DQL-style actor update), numpy, manual backprop.
+
+TEST INFRASTRUCTURE ONLY (same rules as flowrl_oracle.py).  PARITY UNPINNED by the reference: it has no
+tests; what it does is ``jax.grad`` through the unrolled scan of ``DDPM.sample(training=True, params=p)``
+(flowrl/agent/offline/dql.py:93-123, flowrl/module/model.py:78-86, flowrl/flow/ddpm.py:186-219).  This file
+restates that derivative by hand; tests pin it with central finite differences in float64 and with torch
+autograd over an independent restatement (tests/test_oracle_vjp.py).
+
+    loss = sum(g * x0(theta))      =>      returns d loss / d theta   (theta = the Flax parameter tree)
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+import flowrl_oracle as orc
+
+
+# ---- activations and their derivatives -------------------------------------------------------------
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def act_grad(name: str, x):
+    if name == "mish":
+        sp = np.logaddexp(x, 0.0)
+        t = np.tanh(sp)
+        return t + x * (1.0 - t * t) * _sigmoid(x)
+    if name == "silu":
+        s = _sigmoid(x)
+        return s * (1.0 + x * (1.0 - s))
+    if name == "relu":
+        return (x > 0).astype(x.dtype)
+    if name == "tanh":
+        return 1.0 - np.tanh(x) ** 2
+    if name == "elu":
+        return np.where(x > 0, 1.0, np.exp(np.minimum(x, 0.0)))
+    if name == "gelu_tanh":
+        c, k = np.sqrt(2.0 / np.pi), 0.044715
+        u = c * (x + k * x ** 3)
+        th = np.tanh(u)
+        return 0.5 * (1.0 + th) + 0.5 * x * (1.0 - th * th) * c * (1.0 + 3.0 * k * x * x)
+    raise KeyError(name)
+
+
+# ---- network forward with cache / backward ------------------------------------------------------------
+def _mlp_fwd(p, x, n_hidden, act_name, has_output):
+    act = orc.get_activation(act_name)
+    cache = []
+    for i in range(n_hidden):
+        z = x @ p[f"Dense_{i}"]["kernel"] + p[f"Dense_{i}"]["bias"]
+        cache.append((x, z))
+        x = act(z)
+    if has_output:
+        cache.append((x, None))
+        x = x @ p[f"Dense_{n_hidden}"]["kernel"] + p[f"Dense_{n_hidden}"]["bias"]
+    return x, cache
+
+
+def _mlp_bwd(p, cache, gout, n_hidden, act_name, has_output, grads):
+    """Accumulates parameter grads into ``grads`` (same tree layout as p); returns grad wrt the MLP input."""
+    g = gout
+    if has_output:
+        xin, _ = cache[n_hidden]
+        d = grads.setdefault(f"Dense_{n_hidden}", {"kernel": 0.0, "bias": 0.0})
+        d["kernel"] = d["kernel"] + xin.reshape(-1, xin.shape[-1]).T @ g.reshape(-1, g.shape[-1])
+        d["bias"] = d["bias"] + g.reshape(-1, g.shape[-1]).sum(0)
+        g = g @ p[f"Dense_{n_hidden}"]["kernel"].T
+    for i in reversed(range(n_hidden)):
+        xin, z = cache[i]
+        g = g * act_grad(act_name, z)
+        d = grads.setdefault(f"Dense_{i}", {"kernel": 0.0, "bias": 0.0})
+        d["kernel"] = d["kernel"] + xin.reshape(-1, xin.shape[-1]).T @ g.reshape(-1, g.shape[-1])
+        d["bias"] = d["bias"] + g.reshape(-1, g.shape[-1]).sum(0)
+        g = g @ p[f"Dense_{i}"]["kernel"].T
+    return g
+
+
+def backbone_fwd(spec: orc.BackboneSpec, params: Dict, x, time, condition):
+    """DDPMBackbone.__call__ (ddpm.py:83-95) keeping what the backward needs."""
+    c = {"time_in": time}
+    if spec.time_embedding is not None:
+        if spec.time_embedding == "positional":
+            temb = orc.positional_embedding(time, spec.time_dim)
+        else:
+            temb = orc.learnable_fourier_embedding(time, params["time_embedding"]["kernel"])
+        tfeat, c["tmlp"] = _mlp_fwd(params["MLP_0"], temb, 2, "mish", False)
+    else:
+        tfeat = time
+    if spec.cond_hidden is not None:
+        condition, c["cmlp"] = _mlp_fwd(params["cond_embedding"], condition, len(spec.cond_hidden), spec.activation, False)
+    parts = [x, tfeat] + ([condition] if condition is not None else [])
+    inputs = np.concatenate(parts, axis=-1)
+    out, c["pred"] = _mlp_fwd(params[spec.predictor_name], inputs, len(spec.hidden_dims), spec.activation, True)
+    c["dims"] = (x.shape[-1], tfeat.shape[-1])
+    return out, c
+
+
+def backbone_bwd(spec: orc.BackboneSpec, params: Dict, c, gout, grads: Dict):
+    gin = _mlp_bwd(params[spec.predictor_name], c["pred"], gout, len(spec.hidden_dims), spec.activation, True,
+                   grads.setdefault(spec.predictor_name, {}))
+    A, Dp = c["dims"]
+    gx, gt, gc = gin[..., :A], gin[..., A:A + Dp], gin[..., A + Dp:]
+    if spec.cond_hidden is not None:
+        _mlp_bwd(params["cond_embedding"], c["cmlp"], gc, len(spec.cond_hidden), spec.activation, False,
+                 grads.setdefault("cond_embedding", {}))
+    if spec.time_embedding is not None:
+        gtemb = _mlp_bwd(params["MLP_0"], c["tmlp"], gt, 2, "mish", False, grads.setdefault("MLP_0", {}))
+        if spec.time_embedding == "learnable_fourier":
+            # temb = [cos f, sin f], f = 2 pi t @ w.T   (time_embedding.py:23-27)
+            w = params["time_embedding"]["kernel"]
+            t = c["time_in"]
+            f = 2 * np.pi * t @ w.T
+            half = w.shape[0]
+            gf = -np.sin(f) * gtemb[..., :half] + np.cos(f) * gtemb[..., half:]
+            gw = (2 * np.pi * t.reshape(-1, t.shape[-1])).T @ gf.reshape(-1, half)     # (in_dim, D/2)
+            d = grads.setdefault("time_embedding", {"kernel": 0.0})
+            d["kernel"] = d["kernel"] + gw.T
+    return gx
+
+
+# ---- chain VJP --------------------------------------------------------------------------------------------
+def ddpm_sample_vjp(spec: orc.BackboneSpec, params: Dict, tables, xT, condition, noise, g, *, steps: int,
+                    solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None):
+    """d sum(g * x0) / d params and / d xT for DDPM.sample (ddpm.py:173-221).  float64 throughout."""
+    dt = np.float64
+    params = orc.cast_tree(params, dt)
+    betas, alphas, alpha_hats, postvars = [np.asarray(a, dtype=dt) for a in tables]
+    xt = np.asarray(xT, dt)
+    cond = None if condition is None else np.asarray(condition, dt)
+    noise = np.asarray(noise, dt)
+    fw = []
+    for j, t in enumerate(range(steps, 0, -1)):
+        tin = np.full((*xt.shape[:-1], 1), float(t), dtype=dt)
+        eps, cache = backbone_fwd(spec, params, xt, tin, cond)
+        ah, ah1, al = alpha_hats[t], alpha_hats[t - 1], alphas[t]
+        if solver == "ddpm":
+            c0, c1 = 1.0 / np.sqrt(ah), np.sqrt(1.0 - ah)
+            x0h = c0 * (xt - c1 * eps)
+            mask = np.ones_like(x0h)
+            if clip_sampler:
+                mask = ((x0h >= x_min) & (x0h <= x_max)).astype(dt)
+                x0h = np.clip(x0h, x_min, x_max)
+            c2, c3, c4 = 1.0 / (1.0 - ah), np.sqrt(ah1) * (1.0 - al), np.sqrt(al) * (1.0 - ah1)
+            xn = c2 * (c3 * x0h + c4 * xt) + float(t > 1) * np.sqrt(postvars[t]) * noise[j]
+            fw.append((cache, mask, (c0, c1, c2, c3, c4)))
+        else:
+            raise NotImplementedError(solver)
+        xt = xn
+    x0 = xt
+    grads: Dict = {}
+    gx = np.asarray(g, dt)
+    for j in reversed(range(steps)):
+        cache, mask, (c0, c1, c2, c3, c4) = fw[j]
+        g_x0h = c2 * c3 * gx * mask
+        geps = -c0 * c1 * g_x0h
+        gx = c2 * c4 * gx + c0 * g_x0h + backbone_bwd(spec, params, cache, geps, grads)
+    return x0, grads, gx

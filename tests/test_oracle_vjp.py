@@ -1,0 +1,82 @@
+"""CPU tests pinning the VJP oracle (oracle/flowrl_oracle_vjp.py): central finite differences in float64 and
+torch autograd over an independent restatement of the whole chain."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import flowrl_oracle as orc
+import flowrl_oracle_vjp as ov
+import helpers as H
+
+
+def _setup(act="mish", temb="positional", clip=True, B=6, T=4, hidden=(32, 32), A=3, S=5, seed=0):
+    spec = orc.BackboneSpec(hidden_dims=list(hidden), x_dim=A, activation=act, time_embedding=temb, time_dim=16)
+    params = orc.cast_tree(orc.make_params(spec, S, seed=seed), np.float64)
+    rng = np.random.default_rng(seed + 1)
+    xT, cond = rng.standard_normal((B, A)), rng.standard_normal((B, S))
+    noise, g = rng.standard_normal((T, B, A)), rng.standard_normal((B, A))
+    tabs = [t.astype(np.float64) for t in orc.ddpm_tables(T, "vp")]
+    kw = dict(steps=T, clip_sampler=clip, x_min=-1.0, x_max=1.0)
+    return spec, params, tabs, xT, cond, noise, g, kw
+
+
+@pytest.mark.parametrize("act", ["mish", "silu", "tanh", "gelu_tanh", "elu"])
+@pytest.mark.parametrize("temb", ["positional", "learnable_fourier"])
+def test_vjp_matches_finite_differences(act, temb):
+    spec, params, tabs, xT, cond, noise, g, kw = _setup(act=act, temb=temb, clip=False)
+    x0, grads, gx = ov.ddpm_sample_vjp(spec, params, tabs, xT, cond, noise, g, **kw)
+    flat, gflat = orc.flatten_tree(params), orc.flatten_tree(grads)
+    assert set(flat) == set(gflat)
+
+    def loss(p):
+        return float(np.sum(g * orc.ddpm_sample(spec, p, tabs, xT, cond, noise, **kw)[0]))
+
+    rng = np.random.default_rng(5)
+    h = 1e-6
+    for name, arr in flat.items():
+        for _ in range(2):
+            idx = tuple(rng.integers(0, s) for s in arr.shape)
+            old = arr[idx]
+            arr[idx] = old + h
+            lp = loss(orc.unflatten_tree(flat))
+            arr[idx] = old - h
+            lm = loss(orc.unflatten_tree(flat))
+            arr[idx] = old
+            fd = (lp - lm) / (2 * h)
+            assert abs(fd - gflat[name][idx]) <= 2e-6 * max(1.0, abs(fd)), (name, idx, fd, gflat[name][idx])
+    # d loss / d xT
+    xp, xm = xT.copy(), xT.copy()
+    xp[1, 2] += h
+    xm[1, 2] -= h
+    fd = (float(np.sum(g * orc.ddpm_sample(spec, params, tabs, xp, cond, noise, **kw)[0]))
+          - float(np.sum(g * orc.ddpm_sample(spec, params, tabs, xm, cond, noise, **kw)[0]))) / (2 * h)
+    assert abs(fd - gx[1, 2]) <= 2e-6 * max(1.0, abs(fd))
+
+
+def test_vjp_matches_torch_autograd_with_clip():
+    spec, params, tabs, xT, cond, noise, g, kw = _setup(act="mish", temb="positional", clip=True, hidden=(64, 64, 64), B=16, T=5)
+    x0, grads, gx = ov.ddpm_sample_vjp(spec, params, tabs, xT, cond, noise, g, **kw)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in orc.flatten_tree(params).items()}
+    xt = torch.tensor(xT, requires_grad=True)
+    x = xt
+    betas, alphas, ah, pv = [torch.tensor(t) for t in tabs]
+    half = 8
+    f = torch.exp(torch.arange(half, dtype=torch.float64) * -(math.log(10000.0) / (half - 1)))
+    for j, t in enumerate(range(kw["steps"], 0, -1)):
+        te = torch.cat([torch.cos(t * f), torch.sin(t * f)]).expand(x.shape[0], -1)
+        for i in range(2):
+            te = torch.nn.functional.mish(te @ tp[f"MLP_0/Dense_{i}/kernel"] + tp[f"MLP_0/Dense_{i}/bias"])
+        hcur = torch.cat([x, te, torch.tensor(cond)], -1)
+        for i in range(3):
+            hcur = torch.nn.functional.mish(hcur @ tp[f"noise_predictor/Dense_{i}/kernel"] + tp[f"noise_predictor/Dense_{i}/bias"])
+        eps = hcur @ tp["noise_predictor/Dense_3/kernel"] + tp["noise_predictor/Dense_3/bias"]
+        x0h = torch.clamp((x - torch.sqrt(1 - ah[t]) * eps) / torch.sqrt(ah[t]), -1.0, 1.0)
+        x = (torch.sqrt(ah[t - 1]) * (1 - alphas[t]) * x0h + torch.sqrt(alphas[t]) * (1 - ah[t - 1]) * x) / (1 - ah[t])
+        x = x + float(t > 1) * torch.sqrt(pv[t]) * torch.tensor(noise[j])
+    (torch.tensor(g) * x).sum().backward()
+    np.testing.assert_allclose(x0, x.detach().numpy(), rtol=1e-10, atol=1e-12)
+    for name, gv in orc.flatten_tree(grads).items():
+        np.testing.assert_allclose(gv, tp[name].grad.numpy(), rtol=1e-8, atol=1e-10, err_msg=name)
+    np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-8, atol=1e-10)
