@@ -161,6 +161,32 @@ def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None
                 raise ValueError(f"time_embedding/kernel {tuple(k.shape)}, expected {(d_time // 2, 1)}")
 
 
+def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip_sampler, x_min, x_max, history,
+             particles):
+    """Descriptor, parameter pointers and schedule pointers of one call (shared by forward and VJP)."""
+    device = xT.device
+    A = xT.shape[-1]
+    n_states, parts, cond2d = _split_condition(xT, condition, particles)
+    cond_dim = 0 if cond2d is None else cond2d.shape[-1]
+    check_param_shapes(network, params, A, cond_dim)
+    keep: list = []
+    desc = build_desc(network, kind=kind, solver=solver, steps=steps, n_states=n_states, particles=parts, x_dim=A,
+                      cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history)
+    fparams = build_params(network, params, device, keep)
+    fs = _lib.FrlSchedule()
+    for name in ("betas", "alphas", "alpha_hats", "postvars", "ts"):
+        t = sched.get(name)
+        if t is not None:
+            t = _f32c(t, device, f"sched.{name}")
+            if t.numel() != steps + 1:
+                raise ValueError(f"sched.{name} has {t.numel()} entries, expected steps+1 = {steps + 1}")
+            keep.append(t)
+            setattr(fs, name, t.data_ptr())
+    if cond2d is not None:
+        cond2d = _f32c(cond2d, device, "condition")
+    return desc, fparams, fs, keep, n_states * parts, cond2d
+
+
 def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None):
@@ -171,31 +197,15 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     device = xT.device
     A = xT.shape[-1]
     lead = tuple(xT.shape[:-1])
-    n_states, parts, cond2d = _split_condition(xT, condition, particles)
-    B = n_states * parts
-    cond_dim = 0 if cond2d is None else cond2d.shape[-1]
-    check_param_shapes(network, params, A, cond_dim)
-    keep: list = []
-    desc = build_desc(network, kind=kind, solver=solver, steps=steps, n_states=n_states, particles=parts, x_dim=A,
-                      cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history)
-    fparams = build_params(network, params, device, keep)
-
-    fs = _lib.FrlSchedule()
-    for name in ("betas", "alphas", "alpha_hats", "postvars", "ts"):
-        t = sched.get(name)
-        if t is not None:
-            t = _f32c(t, device, f"sched.{name}")
-            if t.numel() != steps + 1:
-                raise ValueError(f"sched.{name} has {t.numel()} entries, expected steps+1 = {steps + 1}")
-            keep.append(t)
-            setattr(fs, name, t.data_ptr())
+    desc, fparams, fs, keep, B, cond2d = _marshal(
+        network, params, kind=kind, solver=solver, steps=steps, xT=xT, condition=condition, sched=sched,
+        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=history, particles=particles)
 
     x_in = _f32c(xT.reshape(B, A), device, "xT")
     x0 = torch.empty((B, A), dtype=torch.float32, device=device)
     bufs = _lib.FrlFwdBufs()
     bufs.xT, bufs.x0 = x_in.data_ptr(), x0.data_ptr()
     if cond2d is not None:
-        cond2d = _f32c(cond2d, device, "condition")
         bufs.cond = cond2d.data_ptr()
     if noise is not None:
         if noise.numel() != steps * B * A:
@@ -220,3 +230,111 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     if history:
         return x0, (xt_hist.reshape(steps, *lead, A), eps_hist.reshape(steps, *lead, A))
     return x0, (None, None)
+
+
+# ---- chain VJP -----------------------------------------------------------------------------------------------
+def _mish64(x):
+    return x * torch.tanh(torch.nn.functional.softplus(x))
+
+
+def time_branch_vjp(network, params: Dict, tvals: torch.Tensor, grad_tb: torch.Tensor, x_dim: int) -> Dict:
+    """Gradients of everything that feeds the hoisted bias table tb[j] = bias_0 + tfeat(t_j) @ kernel_0[A:A+D']
+    (ddpm.py:84-91: time_embedding -> MLP_0 (mish, mish) -> concat slice of Dense_0), given dL/dtb from the kernel.
+    Batch-invariant, O(T D^2): a handful of (T, D) float64 matrix ops on the device, differentiated with autograd.
+    Returns a partial grads tree (float32): MLP_0, time_embedding, and the predictor's Dense_0 bias / time rows."""
+    te = network.time_embedding
+    pname = network.predictor_name
+    f64 = torch.float64
+    g = grad_tb.to(f64)
+    W0 = params[pname]["Dense_0"]["kernel"]
+    t = tvals.to(f64).reshape(-1, 1)
+    out: Dict = {pname: {"Dense_0": {"bias": g.sum(0).to(torch.float32)}}}
+    if te is None:
+        out[pname]["Dense_0"]["time_rows"] = (t.T @ g).to(torch.float32)
+        return out
+    D = te.output_dim
+    leaves = {("MLP_0", f"Dense_{i}", n): params["MLP_0"][f"Dense_{i}"][n].detach().to(f64).requires_grad_(True)
+              for i in range(2) for n in ("kernel", "bias")}
+    if isinstance(te, LearnableFourierEmbedding):
+        wk = params["time_embedding"]["kernel"].detach().to(f64).requires_grad_(True)
+        leaves[("time_embedding", "kernel")] = wk
+        f = 2.0 * torch.pi * t @ wk.T                                     # time_embedding.py:23-27
+    else:
+        half = D // 2
+        fr = torch.exp(torch.arange(half, dtype=f64, device=t.device) * -(torch.log(torch.tensor(10000.0, dtype=f64)) / (half - 1)))
+        f = t * fr                                                        # time_embedding.py:11-16
+    temb = torch.cat([torch.cos(f), torch.sin(f)], dim=-1)
+    h = _mish64(temb @ leaves[("MLP_0", "Dense_0", "kernel")] + leaves[("MLP_0", "Dense_0", "bias")])
+    tfeat = _mish64(h @ leaves[("MLP_0", "Dense_1", "kernel")] + leaves[("MLP_0", "Dense_1", "bias")])
+    wt = W0[x_dim:x_dim + D].detach().to(f64).requires_grad_(True)
+    keys = list(leaves)
+    grads = torch.autograd.grad(tfeat @ wt, [leaves[k] for k in keys] + [wt], grad_outputs=g)
+    for k, gv in zip(keys, grads[:-1]):
+        node = out
+        for name in k[:-1]:
+            node = node.setdefault(name, {})
+        node[k[-1]] = gv.to(torch.float32)
+    out[pname]["Dense_0"]["time_rows"] = grads[-1].to(torch.float32)
+    return out
+
+
+def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int, xt_hist: torch.Tensor,
+                    condition: Optional[torch.Tensor], g_x0: torch.Tensor, sched: Dict[str, torch.Tensor],
+                    tvals: torch.Tensor, clip_sampler: bool, x_min, x_max, particles: Optional[int] = None,
+                    want_gxT: bool = True):
+    """dL/dparams (Flax-layout tree) and dL/dxT of one sampler call, given its history[0] and dL/dx0.
+    The O(B) work (recompute + backward sweep + weight-gradient GEMMs) is libflowrl_hip's frl_sampler_bwd; the
+    batch-invariant time branch is finished here from the kernel's dL/dtb (see :func:`time_branch_vjp`)."""
+    lib = _lib.load()
+    if not g_x0.is_cuda:
+        raise RuntimeError("flowrl_hip VJP runs on the GPU only; there is no CPU fallback")
+    device = g_x0.device
+    A = g_x0.shape[-1]
+    lead = tuple(g_x0.shape[:-1])
+    desc, fparams, fs, keep, B, cond2d = _marshal(
+        network, params, kind=kind, solver=solver, steps=steps, xT=g_x0, condition=condition, sched=sched,
+        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles)
+    if xt_hist.numel() != steps * B * A:
+        raise ValueError(f"xt_hist has {xt_hist.numel()} elements, expected (T, ..., A) = {steps * B * A}")
+    xt_hist = _f32c(xt_hist.reshape(steps, B, A), device, "xt_hist")
+    g_in = _f32c(g_x0.reshape(B, A), device, "g_x0")
+    pname = network.predictor_name
+    n = len(network.predictor.hidden_dims)
+    H = int(network.predictor.hidden_dims[0])
+    grads: Dict = {pname: {}}
+    bufs = _lib.FrlBwdBufs()
+    bufs.xt_hist, bufs.g_x0 = xt_hist.data_ptr(), g_in.data_ptr()
+    if cond2d is not None:
+        bufs.cond = cond2d.data_ptr()
+    g_xT = torch.empty((B, A), dtype=torch.float32, device=device) if want_gxT else None
+    if g_xT is not None:
+        bufs.g_xT = g_xT.data_ptr()
+    for i in range(n + 1):
+        k = params[pname][f"Dense_{i}"]
+        gk = torch.empty_like(k["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
+        gb = torch.empty_like(k["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
+        grads[pname][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
+        bufs.grad_kernel[i], bufs.grad_bias[i] = gk.data_ptr(), gb.data_ptr()
+    grad_tb = torch.empty((steps, H), dtype=torch.float32, device=device)
+    bufs.grad_tb = grad_tb.data_ptr()
+
+    need = lib.frl_bwd_workspace_bytes(C.byref(desc))
+    if need == 0:   # invalid / unsupported descriptor: let the entry point say why
+        _lib.check(lib.frl_sampler_bwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs), None, 0, None))
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "this configuration has no VJP kernel")
+    ws = _workspace(need, device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        rc = lib.frl_sampler_bwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs),
+                                 ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc)
+    # time branch (batch-invariant) from dL/dtb
+    tb = time_branch_vjp(network, params, tvals.to(device), grad_tb, A)
+    d0 = grads[pname]["Dense_0"]
+    d0["bias"].copy_(tb[pname]["Dense_0"]["bias"])
+    Dp = 1 if network.time_embedding is None else network.time_embedding.output_dim
+    d0["kernel"][A:A + Dp].copy_(tb[pname]["Dense_0"]["time_rows"])
+    for key in ("MLP_0", "time_embedding"):
+        if key in tb:
+            grads[key] = tb[key]
+    return grads, (g_xT.reshape(*lead, A) if g_xT is not None else None)

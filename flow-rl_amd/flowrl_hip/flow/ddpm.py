@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from .. import _lib, schedules
-from .._sampler import run_sampler
+from .._sampler import run_sampler, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
 
 SUPPORTED_SOLVERS = ["ddim", "ddpm"]   # ddpm.py:16-18
@@ -84,3 +84,22 @@ class DDPM:
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
             particles=particles)
         return rng, x0, hist
+
+    def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                   solver: str = "ddpm", params: Optional[Dict] = None, *, particles: Optional[int] = None,
+                   want_gxT: bool = True) -> Tuple[Dict, Optional[torch.Tensor]]:
+        """VJP of :meth:`sample` w.r.t. the parameter tree and xT: what ``jax.grad`` through
+        ``actor.sample(..., training=True, params=p)`` computes in the DQL actor update (dql.py:93-123 through
+        ddpm.py:186-219).  ``xt_hist`` = history[0] of the forward call (``sample(..., history=True)``),
+        ``g_x0`` = dL/dx0.  Returns (grads in the layout of ``params``, dL/dxT)."""
+        if solver not in SUPPORTED_SOLVERS:
+            raise NotImplementedError(f"Unsupported solver {solver} for {type(self)}")
+        p = params if params is not None else self.params
+        tvals = torch.arange(self.steps, 0, -1, dtype=torch.float64)     # iteration j <-> t = T - j
+        return run_sampler_vjp(
+            self.network, p, kind=_lib.FRL_KIND_DDPM,
+            solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM, steps=self.steps,
+            xt_hist=xt_hist, condition=condition, g_x0=g_x0,
+            sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
+            tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
+            particles=particles, want_gxT=want_gxT)
