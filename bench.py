@@ -44,6 +44,10 @@ WORKLOADS = {
                       "T=20, clip +-1, 8192 states x 64 particles/GPU)", kind="cddpm",
                  A=17, S=376, T=20, B=8192 * 64, particles=64, hidden=[256, 256, 256], act="mish", temb="learnable_fourier",
                  schedule="cosine", clip=True, x_min=-1.0, x_max=1.0, cond_embed=True),
+    # cfg5 (f32 here; BASELINE names a bf16 variant): forward with history + chain VJP + (N>1) one all-reduce of the grads
+    "cfg5": dict(desc="DQL backprop-through-chain VJP (cfg2 shapes: obs 11, act 3, 256x3 mish, vp, T=5, clip +-1, B=262144/GPU), "
+                      "forward+backward, f32", kind="ddpm", A=3, S=11, T=5, B=262144, particles=1, hidden=[256, 256, 256],
+                 act="mish", temb="positional", schedule="vp", clip=True, x_min=-1.0, x_max=1.0, cond_embed=False, vjp=True),
 }
 
 
@@ -83,6 +87,29 @@ def sample(model, w, xT, cond, noise):
     if w["kind"] == "cnf":
         return model.sample(None, xT, cond, particles=p)[1]
     return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p)[1]
+
+
+def vjp_step(model, w, xT, cond, noise, g):
+    """One DQL actor-update worth of sampler work: forward keeping history[0], then the chain VJP."""
+    _, x0, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True)
+    grads, _ = model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False)
+    return x0, grads
+
+
+def vjp_only_ms(model, w, xT, cond, noise, g, iters):
+    """Average duration of the backward call alone (frl_sampler_bwd: prepare + sweep + dW kernels, plus the host's
+    O(T D^2) time-branch autograd), events on the launch stream."""
+    _, _, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True)
+    for _ in range(2):
+        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(xT.device)
+    e0.record()
+    for _ in range(iters):
+        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False)
+    e1.record()
+    torch.cuda.synchronize(xT.device)
+    return e0.elapsed_time(e1) / iters
 
 
 def kernel_only_ms(model, w, xT, cond, noise, iters):
@@ -157,7 +184,11 @@ def cpu_baseline(w, budget_s=15.0):
         cond = np.repeat(rng.standard_normal((Bs // w["particles"], w["S"])).astype(np.float32), w["particles"], axis=0)
         nz = rng.standard_normal((w["T"], Bs, w["A"])).astype(np.float32)
         t0 = time.perf_counter()
-        if w["kind"] == "ddpm":
+        if w.get("vjp"):
+            import flowrl_oracle_vjp as ov
+            ov.ddpm_sample_vjp(spec, params, orc.ddpm_tables(w["T"], w["schedule"]), xT, cond, nz,
+                               rng.standard_normal((Bs, w["A"])), solver="ddpm", **kw)
+        elif w["kind"] == "ddpm":
             orc.ddpm_sample(spec, params, orc.ddpm_tables(w["T"], w["schedule"]), xT, cond, nz, **kw)
         elif w["kind"] == "cddpm":
             orc.continuous_ddpm_sample(spec, params, orc.continuous_tables(w["T"], w["schedule"]), xT, cond, nz, **kw)
@@ -166,13 +197,15 @@ def cpu_baseline(w, budget_s=15.0):
         return time.perf_counter() - t0
 
     probe_B = 4096 if w["hidden"][0] <= 256 else 2048
+    if w.get("vjp"):
+        probe_B = 1024
     run(probe_B)                      # warm-up (BLAS threads, page faults)
     t_probe = run(probe_B)
     Bs = int(min(w["B"], max(probe_B, probe_B * budget_s / max(t_probe, 1e-3))))
-    Bs = max(probe_B, (Bs // 4096) * 4096)
+    Bs = max(probe_B, (Bs // probe_B) * probe_B)
     t = run(Bs)
     return {"value": Bs * w["T"] / t, "unit": "chain-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy float32 oracle (oracle/flowrl_oracle.py), {Bs} of {w['B']} chains x T={w['T']}, "
+            "sample": f"numpy {'float64 manual-backprop oracle (oracle/flowrl_oracle_vjp.py), forward + VJP' if w.get('vjp') else 'float32 oracle (oracle/flowrl_oracle.py)'}, {Bs} of {w['B']} chains x T={w['T']}, "
                       f"one pass, {t:.2f} s, {cores} BLAS threads"}
 
 
@@ -222,7 +255,16 @@ def main():
     xT, cond, noise = make_inputs(w, dev, 1234 + rank)       # this rank's shard of the states
     gathered = torch.empty((world * B, A), device=dev) if world > 1 else None
 
+    vjp = bool(w.get("vjp"))
+    g_x0 = torch.randn((B, A), generator=torch.Generator(device=dev).manual_seed(99 + rank), device=dev) / (world * B) if vjp else None
+
     def step():
+        if vjp:
+            from flowrl_hip import parallel
+            x0, grads = vjp_step(model, w, xT, cond, noise, g_x0)
+            if world > 1 and not args.no_gather:
+                parallel.all_reduce_grads(grads)
+            return x0
         x0 = sample(model, w, xT, cond, noise)
         if world > 1 and not args.no_gather:
             dist.all_gather_into_tensor(gathered, x0)
@@ -253,6 +295,13 @@ def main():
     out = None
     if rank == 0:
         k_ms, flops_alg, flops_exec = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
+        kname = "frl_sampler_rs_kernel"
+        if vjp:
+            # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
+            b_ms = vjp_only_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
+            kname = "frl_sampler_rs_kernel (no history) + frl_sampler_bwd call (frl_bwd_sweep_kernel + frl_bwd_dw_kernel)"
+            flops_exec = 4.0 * flops_exec
+            flops_alg, k_ms = 3.0 * flops_alg, k_ms + b_ms
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "action samples/sec x T steps (chain-steps/s), fused sampler",
@@ -260,10 +309,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
-                       "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else "all_gather(x0)"},
+                       "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "frl_sampler_rs_kernel", "kernel_ms": k_ms,
+                         "kernel": kname, "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_executed_mfma": flops_exec,
                          "achieved_executed": flops_exec / (k_ms * 1e-3) / 1e12},
         }

@@ -56,3 +56,31 @@ def sample_sharded(sample_fn: Callable, xT: torch.Tensor, condition: Optional[to
         return x0
     counts = [(shard_bounds(n_states, r, world)[1] - shard_bounds(n_states, r, world)[0]) * particles for r in range(world)]
     return all_gather_ragged(x0, counts, group)
+
+
+def _leaves(tree, prefix=()):
+    for k in sorted(tree):
+        v = tree[k]
+        if isinstance(v, dict):
+            yield from _leaves(v, prefix + (k,))
+        else:
+            yield prefix + (k,), v
+
+
+def all_reduce_grads(grads: dict, group=None) -> dict:
+    """Sum a gradient tree over the ranks with ONE all-reduce of the flat f32 buffer (VJP
+    collective: 152,579 + 8,320 parameters = 0.64 MB for DQL -> latency-bound; one bucket, never one collective per
+    leaf).  The loss of the reference's actor update is a mean over the global batch (dql.py:112-118): the caller
+    folds 1/global_batch into the cotangent, so a plain sum is what is needed here.  In place; returns ``grads``."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return grads
+    items = list(_leaves(grads))
+    flat = torch.cat([v.reshape(-1) for _, v in items])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for _, v in items:
+        n = v.numel()
+        v.copy_(flat[o:o + n].view_as(v))
+        o += n
+    return grads

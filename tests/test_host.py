@@ -143,3 +143,42 @@ def test_sharded_sampling_two_ranks_gloo(tmp_path, n_states, particles):
     port = 29500 + (os.getpid() + n_states) % 2000
     mp.spawn(_gloo_worker, args=(2, port, n_states, particles, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _gloo_grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    import torch.distributed as dist
+    import flowrl_oracle as orc
+    import flowrl_oracle_vjp as ov
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the VJP's N>1 contract: every rank differentiates its own block of states, ONE all-reduce sums the flat buffer
+        spec = orc.BackboneSpec(hidden_dims=[32, 32], x_dim=3, activation="mish", time_embedding="positional", time_dim=16)
+        params = orc.make_params(spec, 5, seed=0)
+        tables = orc.ddpm_tables(3, "vp")
+        rng = np.random.default_rng(0)
+        n = 10
+        xT, cond = rng.standard_normal((n, 3)), rng.standard_normal((n, 5))
+        noise, g = rng.standard_normal((3, n, 3)), rng.standard_normal((n, 3))
+        kw = dict(steps=3, clip_sampler=True, x_min=-1.0, x_max=1.0)
+        _, want, _ = ov.ddpm_sample_vjp(spec, params, tables, xT, cond, noise, g, **kw)
+        lo, hi = parallel.shard_bounds(n, rank, world)
+        _, mine, _ = ov.ddpm_sample_vjp(spec, params, tables, xT[lo:hi], cond[lo:hi], noise[:, lo:hi], g[lo:hi], **kw)
+        to_t = lambda t: {k: to_t(v) if isinstance(v, dict) else torch.from_numpy(np.ascontiguousarray(v)) for k, v in t.items()}
+        got = parallel.all_reduce_grads(to_t(mine))
+        for path, v in parallel._leaves(got):
+            ref = want
+            for k in path:
+                ref = ref[k]
+            assert np.allclose(v.numpy(), ref, rtol=1e-10, atol=1e-12), path
+        Path(out_dir, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_allreduce_two_ranks_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_gloo_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
