@@ -160,6 +160,17 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     return e0.elapsed_time(e1) / iters, flops_alg, flops_exec.value
 
 
+def pmc_traffic_bytes(workload, w):
+    """HBM bytes per launch of the sampler kernel from the committed rocprofv3 PMC passes (scripts/prof.sh ->
+    profiles/r01_prof_b/pmc_summary.json; cfg2 at its full batch only): 2 x FETCH_SIZE (gfx950 half-count
+    correction, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KiB.  None when no profile matches."""
+    f = ROOT / "profiles" / "r01_prof_b" / "pmc_summary.json"
+    if workload != "cfg2" or w["B"] != WORKLOADS["cfg2"]["B"] or not f.exists():
+        return None
+    pm = json.loads(f.read_text())
+    return (2.0 * pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0
+
+
 def cpu_baseline(w, budget_s=15.0):
     """The numpy float32 oracle (a port of the reference's arithmetic; the JAX reference itself cannot
     run here) timed on this box's host cores over a bounded sample of the same workload."""
@@ -311,7 +322,9 @@ def main():
             "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
                        "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None if (vjp or args.act or args.layers) else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",
+                         "algorithmic_hbm_bytes": B * (4 * (2 * A + (T * A if w["kind"] != "cnf" else 0)) + 4 * S // w["particles"]),
                          "kernel": kname, "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_executed_mfma": flops_exec,
                          "achieved_executed": flops_exec / (k_ms * 1e-3) / 1e12},
