@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x16_bf16, 32 cycles)
 
 WORKLOADS = {
     # BASELINE.json configs[0..3]; B = chains per GPU (n_states * particles)
@@ -84,9 +85,10 @@ def make_inputs(w, device, seed):
 
 def sample(model, w, xT, cond, noise):
     p = w["particles"] if w["particles"] > 1 else None
+    cd = w.get("dtype", "f32")
     if w["kind"] == "cnf":
-        return model.sample(None, xT, cond, particles=p)[1]
-    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p)[1]
+        return model.sample(None, xT, cond, particles=p, compute_dtype=cd)[1]
+    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd)[1]
 
 
 def vjp_step(model, w, xT, cond, noise, g):
@@ -124,7 +126,8 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     kind = {"ddpm": _lib.FRL_KIND_DDPM, "cddpm": _lib.FRL_KIND_CDDPM, "cnf": _lib.FRL_KIND_CNF}[w["kind"]]
     desc = _sampler.build_desc(model.network, kind=kind, solver=_lib.FRL_SOLVER_EULER if w["kind"] == "cnf" else _lib.FRL_SOLVER_DDPM,
                                steps=w["T"], n_states=w["B"] // w["particles"], particles=w["particles"], x_dim=w["A"],
-                               cond_dim=w["S"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False)
+                               cond_dim=w["S"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False,
+                               compute_dtype=w.get("dtype", "f32"))
     fp = _sampler.build_params(model.network, model.params, dev, keep)
     fs = _lib.FrlSchedule()
     if w["kind"] == "ddpm":
@@ -230,6 +233,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL all-gather of x0 (N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (H = 256 workloads)")
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
@@ -251,6 +256,9 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         w["B"] = args.batch
+    w["dtype"] = args.dtype
+    if args.dtype == "bf16" and w.get("vjp"):
+        raise SystemExit("the chain VJP has no bf16 kernel yet")
     if args.act:
         w["act"] = args.act
     if args.layers > 0:
@@ -260,7 +268,7 @@ def main():
     if args.kernel_only:
         xT, cond, noise = make_inputs(w, dev, 1234)
         k_ms, fa, fe = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
-        print(json.dumps({"kernel_ms": k_ms, "act": w["act"], "layers": len(w["hidden"]), "alg_tflops": fa / k_ms / 1e9,
+        print(json.dumps({"kernel_ms": k_ms, "dtype": args.dtype, "act": w["act"], "layers": len(w["hidden"]), "alg_tflops": fa / k_ms / 1e9,
                           "exec_tflops": fe / k_ms / 1e9}))
         return
     xT, cond, noise = make_inputs(w, dev, 1234 + rank)       # this rank's shard of the states
@@ -314,16 +322,19 @@ def main():
             flops_exec = 4.0 * flops_exec
             flops_alg, k_ms = 3.0 * flops_alg, k_ms + b_ms
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        if args.dtype == "bf16":
+            kname = "frl_sampler_bf16_kernel"
         out = {
             "metric": "action samples/sec x T steps (chain-steps/s), fused sampler",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
                        "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None if (vjp or args.act or args.layers) else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
+                         "traffic": None if (vjp or args.act or args.layers or args.dtype != "f32") else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",
                          "algorithmic_hbm_bytes": B * (4 * (2 * A + (T * A if w["kind"] != "cnf" else 0)) + 4 * S // w["particles"]),
                          "kernel": kname, "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_executed_mfma": flops_exec,

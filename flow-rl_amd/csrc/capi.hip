@@ -46,7 +46,16 @@ static int validate_desc(const FrlDesc* d) {
     if (d->cond_in_dim < 1) { set_error("cond_embed: cond_in_dim %d invalid", d->cond_in_dim); return FRL_EINVAL; }
   }
   // --- what this build has kernels for ---
-  if (d->dtype != FRL_DTYPE_F32) { set_error("bf16 MFMA variant not built yet"); return FRL_EUNSUPPORTED; }
+  if (d->dtype == FRL_DTYPE_BF16) {
+    // bf16 MFMA variant (csrc/sampler_bf16.hip): 256-wide predictor, bf16 operands / f32 accumulate / f32 chain state
+    for (int l = 0; l < d->n_hidden; ++l)
+      if (d->hidden[l] != 256) { set_error("bf16 variant: hidden widths must all be 256 (hidden[%d] = %d)", l, d->hidden[l]); return FRL_EUNSUPPORTED; }
+    if (d->x_dim > 32 || d->cond_dim > 128) { set_error("bf16 variant: x_dim <= 32 and cond_dim <= 128 required (got %d, %d)", d->x_dim, d->cond_dim); return FRL_EUNSUPPORTED; }
+    if (d->act != FRL_ACT_MISH && d->act != FRL_ACT_SILU && d->act != FRL_ACT_RELU && d->act != FRL_ACT_GELU_TANH) {
+      set_error("bf16 variant: activation %d not compiled in (mish / silu / relu / gelu_tanh)", d->act); return FRL_EUNSUPPORTED; }
+    if (bf16_lds_bytes(d->steps, d->n_hidden) > 160 * 1024) { set_error("bf16 variant: steps = %d does not fit the LDS tables", d->steps); return FRL_EUNSUPPORTED; }
+    return FRL_OK;
+  }
   for (int l = 0; l < d->n_hidden; ++l)
     if (d->hidden[l] != d->hidden[0] || (d->hidden[l] != 256 && d->hidden[l] != 512)) {
       set_error("hidden widths must be uniform and 256 or 512 in this build (hidden[%d] = %d)", l, d->hidden[l]);
@@ -106,6 +115,7 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     double em = (double)(pl.XR + 2 * pl.CK) * pl.H;             // Dense_0 without the hoisted time slice, padded
     for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
     em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
+    if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_nck) - (pl.XR + 2 * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
     *executed = 2.0 * B * T * em + cond_flops;
   }
   return 2.0 * B * T * macs + cond_flops;
@@ -143,7 +153,9 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
   pa.plan = pl;
   pa.kind = desc->kind;
   pa.time_embed = desc->time_embed;
-  return launch_prepare(pa, (hipStream_t)hip_stream);
+  rc = launch_prepare(pa, (hipStream_t)hip_stream);
+  if (rc == FRL_OK && pl.bf16) rc = launch_prepare_bf16(*params, pl, (float*)workspace, (hipStream_t)hip_stream);
+  return rc;
 }
 
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
@@ -189,6 +201,11 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
+  if (pl.bf16) {
+    a.ws_bf16 = ws + pl.off_bf16;
+    a.bf_nxk = pl.bf_nxk; a.bf_nck = pl.bf_nck; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
+    return launch_sampler_bf16(*desc, a, (hipStream_t)hip_stream);
+  }
   // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)
   static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
   if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU)

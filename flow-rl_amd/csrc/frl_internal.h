@@ -21,6 +21,8 @@ constexpr int COEF_STRIDE = 8;        // floats per step in the coefficient tabl
 constexpr int MAX_WAVES = 4;          // waves per workgroup (one per SIMD)
 constexpr int COND_EMBED_DIM = 128;   // width of both cond_embedding layers in every reference agent
 constexpr int LAST_PAD = 32;          // last layer is zero-padded to 32 output rows (one MFMA block)
+constexpr int BF_CHUNK_BYTES = 32768; // bf16 variant: one LDS ring slot = 32 A-operand pieces of 1 KB (4 k-steps x 8 output blocks)
+constexpr int BF_NBUF = 4;            // ring depth (3 chunks in flight)
 
 // per-step update modes (ws coef table is built for exactly one of them)
 enum Mode : int {
@@ -54,6 +56,13 @@ struct Plan {
   // workspace layout (float offsets)
   size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, total_floats;
   size_t w0p_rows;
+  // bf16 MFMA variant (32x32x16, hidden width 256): weight stream image = bf_ns chunks of 32 KB per step
+  int bf16;             // 1: desc.dtype == FRL_DTYPE_BF16
+  int bf_nxk;           // layer-0 x k-steps (16 action rows each): 1 (A <= 16 and C <= 32) or 2
+  int bf_nck;           // layer-0 cond k-steps = ceil(C / 16)
+  int bf_l0c;           // layer-0 chunks = ceil((nxk + nck) / 4)
+  int bf_ns;            // chunks per step = l0c + 4 (L - 1) + 1
+  size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
 };
 
 inline int plan_from_desc(const FrlDesc& d, Plan& p) {
@@ -86,6 +95,12 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.off_wlq = take((size_t)p.H * 64);         // per-lane packed image: H/TR * NR/4 loads x 64 lanes x 4 floats
   p.off_blp = take(LAST_PAD);
   p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
+  p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
+  p.bf_nck = (p.C + 15) / 16;
+  p.bf_nxk = (p.A <= 16 && p.bf_nck <= 2) ? 1 : 2;   // the wide instantiation always runs 2 x k-steps
+  p.bf_l0c = (p.bf_nxk + p.bf_nck + 3) / 4;
+  p.bf_ns = p.bf_l0c + 4 * (p.L - 1) + 1;
+  p.off_bf16 = take(p.bf16 ? (size_t)p.bf_ns * (BF_CHUNK_BYTES / 4) : 0);
   p.total_floats = o;
   return 0;
 }
@@ -102,6 +117,8 @@ struct KArgs {
   int w0p_bytes;
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;
+  const void* ws_bf16;                    // bf16 weight stream image (bf16 variant only)
+  int bf_nxk, bf_nck, bf_l0c, bf_ns;
 };
 
 // Arguments of the prepare kernel.
@@ -168,6 +185,9 @@ void set_error(const char* fmt, ...);
 int launch_prepare(const PArgs& a, hipStream_t stream);
 int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);   // LDS K-slab variant (H = 256 only), A/B reference
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
+int launch_prepare_bf16(const FrlParams& p, const Plan& pl, float* ws, hipStream_t stream);   // bf16 weight stream image
+int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256)
+size_t bf16_lds_bytes(int T, int L);
 int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim, const float* w0, const float* b0,
                        const float* w1, const float* b1, float* cfeat, hipStream_t stream);
 int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);

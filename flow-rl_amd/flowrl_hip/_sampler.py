@@ -57,7 +57,8 @@ def _split_condition(xT: torch.Tensor, condition: Optional[torch.Tensor], partic
 
 
 def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, particles: int, x_dim: int,
-               cond_dim: int, clip_sampler: bool, x_min, x_max, want_history: bool) -> _lib.FrlDesc:
+               cond_dim: int, clip_sampler: bool, x_min, x_max, want_history: bool,
+               compute_dtype: str = "f32") -> _lib.FrlDesc:
     pred = network.predictor
     ce = network.cond_embedding
     if ce is not None:
@@ -96,7 +97,9 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
     d.clip = 1 if clip_sampler else 0
     d.x_min = float(x_min) if x_min is not None else 0.0
     d.x_max = float(x_max) if x_max is not None else 0.0
-    d.dtype = _lib.FRL_DTYPE_F32
+    if compute_dtype not in ("f32", "bf16"):
+        raise ValueError(f"compute_dtype {compute_dtype!r}: 'f32' (bit-faithful) or 'bf16' (stated-tolerance MFMA variant)")
+    d.dtype = _lib.FRL_DTYPE_BF16 if compute_dtype == "bf16" else _lib.FRL_DTYPE_F32
     d.want_history = 1 if want_history else 0
     return d
 
@@ -162,7 +165,7 @@ def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None
 
 
 def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip_sampler, x_min, x_max, history,
-             particles):
+             particles, compute_dtype="f32"):
     """Descriptor, parameter pointers and schedule pointers of one call (shared by forward and VJP)."""
     device = xT.device
     A = xT.shape[-1]
@@ -171,7 +174,8 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
     check_param_shapes(network, params, A, cond_dim)
     keep: list = []
     desc = build_desc(network, kind=kind, solver=solver, steps=steps, n_states=n_states, particles=parts, x_dim=A,
-                      cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history)
+                      cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history,
+                      compute_dtype=compute_dtype)
     fparams = build_params(network, params, device, keep)
     fs = _lib.FrlSchedule()
     for name in ("betas", "alphas", "alpha_hats", "postvars", "ts"):
@@ -189,8 +193,10 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
 
 def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
-                clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None):
-    """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored."""
+                clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
+                compute_dtype: str = "f32"):
+    """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored.  ``compute_dtype`` = "bf16"
+    selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful)."""
     lib = _lib.load()
     if not xT.is_cuda:
         raise RuntimeError("flowrl_hip samplers run on the GPU only (xT must be a CUDA/HIP tensor); there is no CPU fallback")
@@ -199,7 +205,8 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     lead = tuple(xT.shape[:-1])
     desc, fparams, fs, keep, B, cond2d = _marshal(
         network, params, kind=kind, solver=solver, steps=steps, xT=xT, condition=condition, sched=sched,
-        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=history, particles=particles)
+        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=history, particles=particles,
+        compute_dtype=compute_dtype)
 
     x_in = _f32c(xT.reshape(B, A), device, "xT")
     x0 = torch.empty((B, A), dtype=torch.float32, device=device)

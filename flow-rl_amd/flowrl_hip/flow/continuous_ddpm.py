@@ -56,7 +56,7 @@ class ContinuousDDPM:
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
-               particles: Optional[int] = None):
+               particles: Optional[int] = None, compute_dtype: str = "f32"):
         """ContinuousDDPM.sample (continuous_ddpm.py:117-222)."""
         steps = steps or self.steps
         t_schedule_n = t_schedule_n or self.t_schedule_n
@@ -77,5 +77,5 @@ class ContinuousDDPM:
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
             sched={"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)},
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles)
+            particles=particles, compute_dtype=compute_dtype)
         return rng, x0, hist

@@ -65,12 +65,13 @@ class DDPM:
 
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: str = "ddpm", params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None,
-               history: bool = False, particles: Optional[int] = None
+               history: bool = False, particles: Optional[int] = None, compute_dtype: str = "f32"
                ) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
         """DDPM.sample (ddpm.py:173-221).  Extra keyword-only arguments:
         ``noise`` (T, *xT.shape): the per-iteration N(0, I) draws (iteration j <-> t = T - j);
         ``history``: also return (xt_hist, eps_hist) (ddpm.py:217); ``particles``: chains per condition
-        row when ``condition`` is passed un-repeated."""
+        row when ``condition`` is passed un-repeated; ``compute_dtype`` = "bf16" selects the bf16-MFMA variant (stated
+        tolerance, see tests/test_gpu_bf16.py) instead of the bit-faithful f32 kernel."""
         if solver not in SUPPORTED_SOLVERS:
             raise NotImplementedError(f"Unsupported solver {solver} for {type(self)}")
         p = params if (training and params is not None) else self.params   # ddpm.py:191-196
@@ -82,7 +83,7 @@ class DDPM:
             steps=self.steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles)
+            particles=particles, compute_dtype=compute_dtype)
         return rng, x0, hist
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,

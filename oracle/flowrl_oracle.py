@@ -240,6 +240,31 @@ class BackboneSpec:
     time_dim: int = 64
     cond_hidden: Optional[Sequence[int]] = None     # cond_embedding MLP hidden dims (dacer.py:263-266) or None
     predictor_name: str = "noise_predictor"         # "vel_predictor" for FlowBackbone
+    bf16_operands: bool = False                     # emulate the bf16-MFMA variant: predictor Dense operands rounded to
+                                                    # bf16 (RNE), products / sums / biases / time slice / activations exact
+
+
+def bf16_round(a):
+    """Round to the nearest bfloat16 (ties to even), returned in a's dtype."""
+    a = np.asarray(a)
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return u.view(np.float32).astype(a.dtype)
+
+
+def _predictor_bf16(spec, p, x, time, condition, act):
+    """The predictor MLP as the bf16 kernel computes it: layer inputs and kernels rounded to bf16, except the time
+    slice of Dense_0, which the kernel folds (in f32) into the per-step bias table."""
+    A, Dp = x.shape[-1], time.shape[-1]
+    W0 = p["Dense_0"]["kernel"]
+    z = bf16_round(x) @ bf16_round(W0[:A]) + time @ W0[A:A + Dp] + p["Dense_0"]["bias"]
+    if condition is not None:
+        z = z + bf16_round(condition) @ bf16_round(W0[A + Dp:])
+    n = len(spec.hidden_dims)
+    h = act(z)
+    for i in range(1, n):
+        h = act(bf16_round(h) @ bf16_round(p[f"Dense_{i}"]["kernel"]) + p[f"Dense_{i}"]["bias"])
+    return bf16_round(h) @ bf16_round(p[f"Dense_{n}"]["kernel"]) + p[f"Dense_{n}"]["bias"]
 
 
 def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
@@ -254,6 +279,8 @@ def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
         time = mlp_apply(params["MLP_0"], time, 2, mish, has_output=False)
     if spec.cond_hidden is not None:
         condition = mlp_apply(params["cond_embedding"], condition, len(spec.cond_hidden), act, has_output=False)
+    if spec.bf16_operands:
+        return _predictor_bf16(spec, params[spec.predictor_name], x, time, condition, act)
     if condition is not None:
         inputs = np.concatenate([x, time, condition], axis=-1)
     else:

@@ -29,13 +29,15 @@ class Case:
     particles: int = 1
     seed: int = 0
     cond_embed: bool = False       # cond_embedding MLP(128,128): S is then the RAW obs width
+    bf16: bool = False             # bf16-MFMA variant (product) / bf16-operand emulation (oracle)
 
     @property
     def spec(self):
         return orc.BackboneSpec(hidden_dims=list(self.hidden), x_dim=self.A, activation=self.act,
                                 time_embedding=self.temb, time_dim=64,
                                 cond_hidden=[128, 128] if self.cond_embed else None,
-                                predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor")
+                                predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor",
+                                bf16_operands=self.bf16)
 
 
 def make_inputs(c: Case):
@@ -101,7 +103,8 @@ def product_run(c: Case, model, xT, cond, noise, device="cuda", history=True):
     x = torch.from_numpy(xT).to(device)
     cd = None if cond is None else torch.from_numpy(cond).to(device)
     nz = torch.from_numpy(noise).to(device)
-    kw = dict(history=history, particles=c.particles if c.particles > 1 else None)
+    kw = dict(history=history, particles=c.particles if c.particles > 1 else None,
+              compute_dtype="bf16" if c.bf16 else "f32")
     if c.kind == "ddpm":
         _, x0, (xh, eh) = model.sample(None, x, cd, False, c.solver, noise=nz, **kw)
     elif c.kind == "cddpm":

@@ -74,7 +74,9 @@ def test_algorithmic_flops_match_survey(lib):
     (dict(x_min=2.0, x_max=1.0), _lib.FRL_EINVAL),
     (dict(kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_DDPM), _lib.FRL_EINVAL),
     (dict(solver=5), _lib.FRL_EUNSUPPORTED),
-    (dict(dtype=_lib.FRL_DTYPE_BF16), _lib.FRL_EUNSUPPORTED),
+    (dict(dtype=_lib.FRL_DTYPE_BF16, x_dim=33), _lib.FRL_EUNSUPPORTED),
+    (dict(dtype=_lib.FRL_DTYPE_BF16, act=_lib.FRL_ACT["tanh"]), _lib.FRL_EUNSUPPORTED),
+    (dict(dtype=7), _lib.FRL_EINVAL),
     (dict(x_dim=40), _lib.FRL_EUNSUPPORTED),
 ])
 def test_bad_descriptors_rejected(lib, kw, code):

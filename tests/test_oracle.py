@@ -258,3 +258,12 @@ def test_oracle_reproduces_golden(case):
     # float32 oracle stays within the parity tolerance of the stored float64 answer
     r32 = H.oracle_run(case, params, z["xT"], z["cond"], z["noise"], np.float32)
     assert H.rel_err(r32[0], z["x0"]) < 2e-5
+
+
+def test_bf16_round_matches_torch():
+    import torch
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.integers(-6, 6, 4096), [0.0, 1.0, 1.00390625, -1.01171875]])
+    want = torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    assert np.array_equal(orc.bf16_round(a), want)
+    assert orc.bf16_round(a.astype(np.float32)).dtype == np.float32
