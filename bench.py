@@ -158,6 +158,8 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
         _lib.check(lib.frl_sampler_run(C.byref(desc), C.byref(fp), C.byref(bufs), ws.data_ptr(), need, stream))
     e1.record()
     torch.cuda.synchronize(dev)
+    if os.environ.get("FRL_DUMP_X0"):      # section cycle counters of an instrumented build (development aid)
+        print("x0[:6] =", x0.reshape(-1)[:6].tolist(), file=sys.stderr)
     flops_exec = C.c_double(0.0)
     flops_alg = lib.frl_algorithmic_flops(C.byref(desc), C.byref(flops_exec))
     return e0.elapsed_time(e1) / iters, flops_alg, flops_exec.value

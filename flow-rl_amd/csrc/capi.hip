@@ -115,7 +115,7 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     double em = (double)(pl.XR + 2 * pl.CK) * pl.H;             // Dense_0 without the hoisted time slice, padded
     for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
     em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
-    if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_nck) - (pl.XR + 2 * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
+    if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_cks) - (pl.XR + 2 * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
     *executed = 2.0 * B * T * em + cond_flops;
   }
   return 2.0 * B * T * macs + cond_flops;
@@ -203,7 +203,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
   if (pl.bf16) {
     a.ws_bf16 = ws + pl.off_bf16;
-    a.bf_nxk = pl.bf_nxk; a.bf_nck = pl.bf_nck; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
+    a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
     return launch_sampler_bf16(*desc, a, (hipStream_t)hip_stream);
   }
   // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)

@@ -59,8 +59,8 @@ struct Plan {
   // bf16 MFMA variant (32x32x16, hidden width 256): weight stream image = bf_ns chunks of 32 KB per step
   int bf16;             // 1: desc.dtype == FRL_DTYPE_BF16
   int bf_nxk;           // layer-0 x k-steps (16 action rows each): 1 (A <= 16 and C <= 32) or 2
-  int bf_nck;           // layer-0 cond k-steps = ceil(C / 16)
-  int bf_l0c;           // layer-0 chunks = ceil((nxk + nck) / 4)
+  int bf_cks;           // layer-0 cond k-steps the instantiation runs (2 or 8; k-steps beyond ceil(C / 16) are zero)
+  int bf_l0c;           // layer-0 chunks = ceil(8 (nxk + cks) / 32)
   int bf_ns;            // chunks per step = l0c + 4 (L - 1) + 1
   size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
 };
@@ -96,9 +96,9 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.off_blp = take(LAST_PAD);
   p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
-  p.bf_nck = (p.C + 15) / 16;
-  p.bf_nxk = (p.A <= 16 && p.bf_nck <= 2) ? 1 : 2;   // the wide instantiation always runs 2 x k-steps
-  p.bf_l0c = (p.bf_nxk + p.bf_nck + 3) / 4;
+  p.bf_nxk = (p.A <= 16 && p.C <= 32) ? 1 : 2;   // narrow instantiation <8, 2> or wide <16, 8>
+  p.bf_cks = (p.bf_nxk == 1) ? 2 : 8;
+  p.bf_l0c = (8 * (p.bf_nxk + p.bf_cks) + 31) / 32;
   p.bf_ns = p.bf_l0c + 4 * (p.L - 1) + 1;
   p.off_bf16 = take(p.bf16 ? (size_t)p.bf_ns * (BF_CHUNK_BYTES / 4) : 0);
   p.total_floats = o;
@@ -118,7 +118,7 @@ struct KArgs {
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;
   const void* ws_bf16;                    // bf16 weight stream image (bf16 variant only)
-  int bf_nxk, bf_nck, bf_l0c, bf_ns;
+  int bf_nxk, bf_cks, bf_l0c, bf_ns;
 };
 
 // Arguments of the prepare kernel.

@@ -12,15 +12,19 @@
 // of the next layer — activations still never leave the register file.  The k <-> feature map this implies,
 //     feature(block, q, s, e) = 32 block + (e&3) + 8 (2q + (e>>2)) + 4 s,
 // is baked into the weight image: frl_prepare_bf16_kernel writes, per step, a stream of 1 KB A-operand "pieces"
-// (64 lanes x 8 bf16: lane (i, s) holds W[feature(.., s, e)][32 ob + i], e = 0..7), 8 pieces (ob = 0..7) per k-step,
-// in exactly the order the kernel consumes them.
+// (64 lanes x 8 bf16: lane (i, s) holds W[feature(.., s, e)][32 ob + i], e = 0..7) in exactly the order the kernel
+// consumes them: OUTPUT-BLOCK-MAJOR (for ob: for k-step), so that a wave finishes one 32-feature output block at a
+// time (16 MFMAs into ONE accumulator), activates + packs it (-> two k-steps of the next layer's B operand) while
+// the next block's MFMAs run, and never holds a whole layer of f32 accumulators: 64 registers of packed inputs,
+// 64 of packed outputs, 2 x 16 accumulators.  That fits 256 registers, i.e. TWO waves per SIMD — which is the
+// point: measured (scripts/ubench/act_mix.hip and the first version of this kernel), VALU work issued by the wave
+// that owns the MFMA stream is NOT hidden behind it (k-step = 256 cycles of MFMA + ~3.6 cycles per VALU
+// instruction, additive); a second wave on the SIMD is what overlaps one wave's activation with the other's MFMAs.
 //
-// One buffer_load per MFMA is NOT viable here (measured: 64 cycles per 32-cycle MFMA, scripts/ubench), so the
-// stream goes through LDS: 32 KB chunks (4 k-steps) by LDS-DMA into a 4-slot ring, three chunks in flight, one
-// s_barrier per chunk, read back with one ds_read_b128 per MFMA (measured free beside the MFMA).  The kernel is
-// VALU-bound (activation: 7 VALU + cvt per element vs 1 MFMA per 8 elements): plain f32 ops only, because
-// v_pk_*_f32 beside bf16 MFMAs is an anti-lever (measured +8.5 cycles each) — this TU is built with
-// -fno-slp-vectorize so the compiler does not pack them either.
+// One buffer_load per MFMA is NOT viable (measured: 64 cycles per 32-cycle MFMA), so the stream goes through LDS:
+// 32 KB chunks (2 output blocks) by LDS-DMA into a 4-slot ring, three chunks in flight, one s_barrier per chunk,
+// read back with one ds_read_b128 per MFMA.  Plain f32 VALU only: v_pk_*_f32 beside bf16 MFMAs is an anti-lever
+// (measured +8.5 cycles each) — this TU is built with -fno-slp-vectorize so the compiler does not pack either.
 #include "frl_device.h"
 
 namespace frl {
@@ -40,7 +44,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {   // round to nearest 
 struct PBfArgs {
   const float* kernel[FRL_MAX_HIDDEN + 1];
   unsigned short* img;
-  int A, C, Dp, L, nxk, nck, l0c, ns;
+  int A, C, Dp, L, nxk, k0, l0c, ns;   // k0 = layer-0 k-steps per output block (x k-steps + compiled cond k-steps)
 };
 
 __global__ void __launch_bounds__(256) frl_prepare_bf16_kernel(const PBfArgs p) {
@@ -52,18 +56,21 @@ __global__ void __launch_bounds__(256) frl_prepare_bf16_kernel(const PBfArgs p) 
     const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
     const int i = lane & 31, s = lane >> 5;
     float v = 0.0f;
-    if (c < p.l0c) {                                   // Dense_0: x k-steps, then cond k-steps (time rows are in tb)
-      const int ks = c * 4 + (piece >> 3), ob = piece & 7;
-      if (ks < p.nxk) {
-        const int row = BF_ROWR(8 * ks + e) + 4 * s;
-        if (row < p.A) v = p.kernel[0][(size_t)row * H + 32 * ob + i];
-      } else if (ks < p.nxk + p.nck) {
-        const int ci = 16 * (ks - p.nxk) + 8 * s + e;
-        if (ci < p.C) v = p.kernel[0][(size_t)(p.A + p.Dp + ci) * H + 32 * ob + i];
+    if (c < p.l0c) {                                   // Dense_0: per output block, x k-steps then cond k-steps
+      const int pi = c * 32 + piece;                   //   (time rows are in tb; k-steps beyond the data are zero)
+      const int ob = pi / p.k0, ks = pi - ob * p.k0;
+      if (ob < 8) {
+        if (ks < p.nxk) {
+          const int row = BF_ROWR(8 * ks + e) + 4 * s;
+          if (row < p.A) v = p.kernel[0][(size_t)row * H + 32 * ob + i];
+        } else {
+          const int ci = 16 * (ks - p.nxk) + 8 * s + e;
+          if (ci < p.C) v = p.kernel[0][(size_t)(p.A + p.Dp + ci) * H + 32 * ob + i];
+        }
       }
-    } else if (c < p.l0c + 4 * (p.L - 1)) {            // hidden Dense_l
+    } else if (c < p.l0c + 4 * (p.L - 1)) {            // hidden Dense_l: chunk = output blocks 2 hc, 2 hc + 1
       const int hc = c - p.l0c, l = 1 + (hc >> 2);
-      const int ks = (hc & 3) * 4 + (piece >> 3), ob = piece & 7;
+      const int ob = 2 * (hc & 3) + (piece >> 4), ks = piece & 15;
       const int feat = 32 * (ks >> 1) + BF_ROWR(8 * (ks & 1) + e) + 4 * s;
       v = p.kernel[l][(size_t)feat * H + 32 * ob + i];
     } else if (piece < 16) {                           // Dense_L, one output block (rows >= A are zero)
@@ -80,7 +87,7 @@ int launch_prepare_bf16(const FrlParams& prm, const Plan& pl, float* ws, hipStre
   for (int l = 0; l <= pl.L; ++l) p.kernel[l] = prm.kernel[l];
   p.img = (unsigned short*)(ws + pl.off_bf16);
   p.A = pl.A; p.C = pl.C; p.Dp = pl.Dp; p.L = pl.L;
-  p.nxk = pl.bf_nxk; p.nck = pl.bf_nck; p.l0c = pl.bf_l0c; p.ns = pl.bf_ns;
+  p.nxk = pl.bf_nxk; p.k0 = pl.bf_nxk + pl.bf_cks; p.l0c = pl.bf_l0c; p.ns = pl.bf_ns;
   hipLaunchKernelGGL(frl_prepare_bf16_kernel, dim3(64), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
@@ -143,47 +150,56 @@ __device__ __forceinline__ void dma16_bf(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
 }
 
-// One hidden Dense layer: 16 k-steps x 8 output blocks.  Operand fetch (8 x ds_read_b128) and the activated,
-// packed B operand of k-step n+1 are produced in the shadow of k-step n's 8 MFMAs; a chunk boundary (barrier +
-// next DMA) every 4 k-steps.
-template <int ACT, typename NextChunk>
-__device__ __forceinline__ void hidden_layer_bf(f32x16 (&Q)[8], const f32x16 (&P)[8], NextChunk& next_chunk, unsigned lane16) {
+// One Dense layer, output-block-major: for each of the NOB output blocks, NK MFMAs into one accumulator; the
+// activation + packing of the previous block (-> bout[2 ob], bout[2 ob + 1]) is issued alongside.  Pieces are read
+// through a 4-deep register ring; a chunk boundary (barrier + next DMA) every 32 pieces.
+template <int ACT, int NK, typename BFun, typename NextChunk>
+__device__ __forceinline__ void layer_bf(u32x4 (&bout)[16], BFun&& bfun, const float* sb, NextChunk& next_chunk,
+                                         unsigned lane16, int ls) {
+  constexpr int NP = 8 * NK, R = 4;
+  f32x16 acc[2];
+  u32x4 ring[R];
   const char* sl = next_chunk() + lane16;
-  u32x4 aw[8], nw[8];
-  sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; aw[ob] = *(const u32x4*)(sl + ob * 1024); });
-  u32x4 bop = pack_act<ACT, 0>(P[0]), nb = bop;
-  sfor<16>([&](auto KI) {
-    constexpr int ks = decltype(KI)::value;
-    if constexpr (ks + 1 < 16) {
-      constexpr int n = ks + 1;
-      if constexpr ((n & 3) == 0) sl = next_chunk() + lane16;
-      sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; nw[ob] = *(const u32x4*)(sl + ((n & 3) * 8 + ob) * 1024); });
-      nb = pack_act<ACT, 8 * (n & 1)>(P[n >> 1]);
+  const char* sl_next = sl;
+  sfor<R>([&](auto PI) { constexpr int p = decltype(PI)::value; ring[p] = *(const u32x4*)(sl + p * 1024); });
+  sfor<8>([&](auto OI) {
+    constexpr int ob = decltype(OI)::value;
+    sfor<4>([&](auto VI) {                               // accumulator init = bias (permuted table: 4 x 16 B per block)
+      constexpr int v = decltype(VI)::value;
+      const f32x4 bv = *(const f32x4*)(sb + (ls * 8 + ob) * 16 + 4 * v);
+      sfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; acc[ob & 1][4 * v + j] = bv[j]; });
+    });
+    if constexpr (ob > 0) {
+      bout[2 * (ob - 1)] = pack_act<ACT, 0>(acc[(ob - 1) & 1]);
+      bout[2 * (ob - 1) + 1] = pack_act<ACT, 8>(acc[(ob - 1) & 1]);
     }
-    sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; Q[ob] = mfma_bf(aw[ob], bop, Q[ob]); });
-    if constexpr (ks + 1 < 16) {
-      // the 8 operand reads go out in the first 4 gaps, so the last one has >= 4 MFMAs (128+ cycles) to land before
-      // k-step n+1 starts (one read per gap left its full LDS latency exposed at every k-step boundary)
-      sfor<4>([&](auto) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 x ds_read (A operands of k-step n+1)
-        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // VALU (activation + pack of k-step n+1)
-      });
-      sfor<4>([&](auto) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+    sfor<NK>([&](auto KI) {
+      constexpr int ks = decltype(KI)::value;
+      constexpr int p = ob * NK + ks;
+      acc[ob & 1] = mfma_bf(ring[p % R], bfun(KI), acc[ob & 1]);
+      if constexpr (p + R < NP) {
+        constexpr int q = p + R;
+        if constexpr ((q & 31) == 0) sl_next = next_chunk() + lane16;   // the ring runs R pieces ahead of the MFMAs
+        ring[p % R] = *(const u32x4*)(sl_next + (q & 31) * 1024);
+      }
+    });
+    if constexpr (ob > 0) {
+      sfor<NK>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // ds_read (piece p + R)
+        __builtin_amdgcn_sched_group_barrier(0x002, (16 * 9 + NK - 1) / NK, 0);   // VALU (activation of block ob - 1)
       });
     }
     __builtin_amdgcn_sched_barrier(0);
-    sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; aw[ob] = nw[ob]; });
-    bop = nb;
   });
+  bout[14] = pack_act<ACT, 0>(acc[1]);
+  bout[15] = pack_act<ACT, 8>(acc[1]);
 }
 
 template <int ACT, int NRX, int CKS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 frl_sampler_bf16_kernel(const KArgs a) {
-  constexpr int H = 256, NXK = NRX / 8;
+  constexpr int H = 256, NXK = NRX / 8, K0 = NXK + CKS, NT = 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -197,25 +213,22 @@ frl_sampler_bf16_kernel(const KArgs a) {
   float* s_bl = s_bh + (a.L - 1) * H;                         // [32] padded last-layer bias (natural order)
   float* s_coef = s_bl + LAST_PAD;                            // [T][8]
   auto perm_src = [](int p) { const int s = p >> 7, ob = (p >> 4) & 7, r = p & 15; return 32 * ob + BF_ROWR(r) + 4 * s; };
-  for (int idx = tid; idx < a.T * H; idx += 256) s_tb[idx] = a.ws_tb[(idx & ~(H - 1)) + perm_src(idx & (H - 1))];
+  for (int idx = tid; idx < a.T * H; idx += NT) s_tb[idx] = a.ws_tb[(idx & ~(H - 1)) + perm_src(idx & (H - 1))];
   for (int l = 1; l < a.L; ++l) {
     const float* bp = pick_ptr_rs(a.bh, l - 1);
-    for (int idx = tid; idx < H; idx += 256) s_bh[(l - 1) * H + idx] = bp[perm_src(idx)];
+    for (int idx = tid; idx < H; idx += NT) s_bh[(l - 1) * H + idx] = bp[perm_src(idx)];
   }
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
-  for (int idx = tid; idx < a.T * COEF_STRIDE; idx += 256) s_coef[idx] = a.ws_coef[idx];
+  for (int idx = tid; idx < a.T * COEF_STRIDE; idx += NT) s_coef[idx] = a.ws_coef[idx];
   __syncthreads();
 
   // ---- weight stream: the same bf_ns chunks every step of every tile, three in flight ----------------------
   const int NS = a.bf_ns;
-  const char* img = (const char*)a.ws_bf16 + wave * 8192 + lane * 16;   // this wave DMAs pieces 8w .. 8w+7 of a chunk
+  const char* img = (const char*)a.ws_bf16 + wave * 4096 + lane * 16;   // this wave DMAs pieces 4w .. 4w+3 of a chunk
   auto issue = [&](int seq, unsigned boff) {
     const char* src = img + (size_t)seq * BF_CHUNK_BYTES;
-    char* dst = smem + boff + wave * 8192;
-    sfor<8>([&](auto II) {
-      constexpr int i = decltype(II)::value;
-      dma16_bf<(i & 3) * 1024>(src + (i >> 2) * 4096, dst + (i >> 2) * 4096);
-    });
+    char* dst = smem + boff + wave * 4096;
+    sfor<4>([&](auto II) { constexpr int i = decltype(II)::value; dma16_bf<i * 1024>(src, dst); });
   };
   auto wrap_seq = [&](int s) { return s >= NS ? s - NS : s; };
   issue(0, 0);
@@ -223,12 +236,16 @@ frl_sampler_bf16_kernel(const KArgs a) {
   issue(wrap_seq(wrap_seq(1) + 1), 2 * BF_CHUNK_BYTES);
   int seq_issue = wrap_seq(wrap_seq(wrap_seq(1) + 1) + 1);
   unsigned boff_issue = 3 * BF_CHUNK_BYTES, boff_cur = 0;
-  // start of a chunk's compute: its DMA has landed (all but the two newer chunks' 16 DMAs of this wave are done),
-  // every wave is past the previous chunk (barrier) so its slot can take the chunk three ahead.
+  // start of a chunk's use: its DMA has landed (all but the two newer chunks' 8 DMAs of this wave are done), every
+  // wave is past the previous chunk (barrier), so that chunk's slot can take the chunk three ahead.
   auto next_chunk = [&]() -> const char* {
-    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+#if !defined(FRL_BF_EXP_NOBAR)   // (timing experiments only: results are wrong without the wait / barrier / DMA)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#endif
+#if !defined(FRL_BF_EXP_NODMA)
     issue(seq_issue, boff_issue);
+#endif
     seq_issue = (seq_issue + 1 == NS) ? 0 : seq_issue + 1;
     boff_issue = (boff_issue + BF_CHUNK_BYTES) & (BF_NBUF * BF_CHUNK_BYTES - 1);
     const char* p = smem + boff_cur;
@@ -237,22 +254,17 @@ frl_sampler_bf16_kernel(const KArgs a) {
   };
 
   const unsigned lane16 = lane * 16;
-  auto bias_init = [&](f32x16 (&Q)[8], const float* sb) {
-    sfor<8>([&](auto OI) {
-      constexpr int ob = decltype(OI)::value;
-      sfor<4>([&](auto VI) {
-        constexpr int v = decltype(VI)::value;
-        const f32x4 bv = *(const f32x4*)(sb + (ls * 8 + ob) * 16 + 4 * v);
-        sfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; Q[ob][4 * v + j] = bv[j]; });
-      });
-    });
-  };
+  const int ntiles = (int)((a.B + 255) / 256);
+  u32x4 bin[16], bout[16];    // packed bf16 layer inputs / outputs: k-step ks <-> features of block ks >> 1, half ks & 1
 
-  f32x16 P[8], Q[8];
-  const int ntiles = (int)((a.B + 127) / 128);
-
+#ifdef FRL_BF_EXP_TIMING
+  long long tsec[6] = {0, 0, 0, 0, 0, 0}; long long tmark = __builtin_amdgcn_s_memtime();
+#define FRL_TMARK(k) { const long long tn = __builtin_amdgcn_s_memtime(); tsec[k] += tn - tmark; tmark = tn; }
+#else
+#define FRL_TMARK(k)
+#endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long chain = (long long)tile * 128 + wave * 32 + li;
+    const long long chain = (long long)tile * 256 + wave * 32 + li;
     const bool valid = chain < a.B;
     const long long state = (a.particles == 1) ? chain : chain / a.particles;
 
@@ -273,69 +285,47 @@ frl_sampler_bf16_kernel(const KArgs a) {
       });
       sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; cbp[kc][w] = pack2(cv[2 * w], cv[2 * w + 1]); });
     });
+    FRL_TMARK(0)
 
     for (int j = 0; j < a.T; ++j) {
-      float zr[NRX];    // noise of this step: issued now, consumed after the last layer
-      sfor<NRX>([&](auto RI) {
-        constexpr int r = decltype(RI)::value;
-        const int ai = BF_ROWR(r) + 4 * ls;
-        zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
-      });
-
-      // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
-      bias_init(P, s_tb + j * H);
+      FRL_TMARK(1)
+      // ---------------- Dense_0 : h_0 = act(tb[j] + W0x^T x + W0c^T cond) -> bin ----------------------
       {
-        const char* sl = next_chunk() + lane16;
+        u32x4 bx[NXK];
         sfor<NXK>([&](auto QI) {
           constexpr int q = decltype(QI)::value;
-          u32x4 bx;
-          sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; bx[w] = pack2(xs[8 * q + 2 * w], xs[8 * q + 2 * w + 1]); });
-          u32x4 aw[8];
-          sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; aw[ob] = *(const u32x4*)(sl + (q * 8 + ob) * 1024); });
-          sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; P[ob] = mfma_bf(aw[ob], bx, P[ob]); });
+          sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; bx[q][w] = pack2(xs[8 * q + 2 * w], xs[8 * q + 2 * w + 1]); });
         });
-        sfor<CKS>([&](auto CI) {
-          constexpr int kc = decltype(CI)::value;
-          constexpr int ks = NXK + kc;
-          if (kc < a.bf_nck) {
-            if constexpr ((ks & 3) == 0) sl = next_chunk() + lane16;
-            u32x4 aw[8];
-            sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; aw[ob] = *(const u32x4*)(sl + ((ks & 3) * 8 + ob) * 1024); });
-            sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; P[ob] = mfma_bf(aw[ob], cbp[kc], P[ob]); });
-          }
-        });
+        auto b0 = [&](auto KI) -> u32x4 {
+          constexpr int ks = decltype(KI)::value;
+          if constexpr (ks < NXK) return bx[ks]; else return cbp[ks - NXK];
+        };
+        layer_bf<ACT, K0>(bin, b0, s_tb + j * H, next_chunk, lane16, ls);
       }
+      FRL_TMARK(2)
 
-      // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P), roles alternate (no copy) ----------
-      int l = 1;
-      for (; l + 1 < a.L; l += 2) {
-        bias_init(Q, s_bh + (l - 1) * H);
-        hidden_layer_bf<ACT>(Q, P, next_chunk, lane16);
-        bias_init(P, s_bh + l * H);
-        hidden_layer_bf<ACT>(P, Q, next_chunk, lane16);
+      // ---------------- hidden Dense_l : h_l = act(b_l + W_l^T h_{l-1}) -------------------------------
+      for (int l = 1; l < a.L; ++l) {
+        auto bh = [&](auto KI) -> u32x4 { return bin[decltype(KI)::value]; };
+        layer_bf<ACT, 16>(bout, bh, s_bh + (l - 1) * H, next_chunk, lane16, ls);
+        sfor<16>([&](auto KI) { constexpr int k = decltype(KI)::value; bin[k] = bout[k]; });
       }
-      if (l < a.L) {
-        bias_init(Q, s_bh + (l - 1) * H);
-        hidden_layer_bf<ACT>(Q, P, next_chunk, lane16);
-        sfor<8>([&](auto OI) { constexpr int ob = decltype(OI)::value; P[ob] = Q[ob]; });
-      }
+      FRL_TMARK(3)
 
-      // ---------------- Dense_L : O = b_L + W_L^T act(P), one output block --------------------------
+      // ---------------- Dense_L : O = b_L + W_L^T h_{L-1}, one output block ----------------------------
       f32x16 O;
       sfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[BF_ROWR(r) + 4 * ls]; });
       {
         const char* sl = next_chunk() + lane16;
-        u32x4 awl[8];   // operand ring, 8 k-steps ahead
-        sfor<8>([&](auto KI) { constexpr int ks = decltype(KI)::value; awl[ks] = *(const u32x4*)(sl + ks * 1024); });
-        u32x4 bop = pack_act<ACT, 0>(P[0]), nb = bop;
+        u32x4 awl[4];
+        sfor<4>([&](auto KI) { constexpr int ks = decltype(KI)::value; awl[ks] = *(const u32x4*)(sl + ks * 1024); });
         sfor<16>([&](auto KI) {
           constexpr int ks = decltype(KI)::value;
-          if constexpr (ks + 1 < 16) nb = pack_act<ACT, 8 * ((ks + 1) & 1)>(P[(ks + 1) >> 1]);
-          O = mfma_bf(awl[ks & 7], bop, O);
-          if constexpr (ks + 8 < 16) awl[ks & 7] = *(const u32x4*)(sl + (ks + 8) * 1024);
-          bop = nb;
+          O = mfma_bf(awl[ks & 3], bin[ks], O);
+          if constexpr (ks + 4 < 16) awl[ks & 3] = *(const u32x4*)(sl + (ks + 4) * 1024);
         });
       }
+      FRL_TMARK(4)
 
       // ---------------- epilogue: one reverse-diffusion / Euler step (f32) ---------------------------
       const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
@@ -346,6 +336,8 @@ frl_sampler_bf16_kernel(const KArgs a) {
         const int ai = BF_ROWR(r) + 4 * ls;
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
+        // noise is read here, not a step ahead: the second wave on the SIMD covers the latency, registers are scarce
+        const float z = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         if (a.xt_hist != nullptr && in) {
           const long long o = ((long long)j * a.B + chain) * a.A + ai;
           a.xt_hist[o] = xt;
@@ -356,7 +348,7 @@ frl_sampler_bf16_kernel(const KArgs a) {
           float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);   // ddpm.py:200-201
           xn = c2 * (c3 * x0h + c4 * xt);                           // ddpm.py:202-203
-          xn += c5 * zr[r];                                         // ddpm.py:206
+          xn += c5 * z;                                             // ddpm.py:206
         } else if (a.mode == MODE_DDPM_DDIM) {
           xn = c0 * (xt - c1 * eps) + c2 * eps;                     // ddpm.py:211
           if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
@@ -364,7 +356,7 @@ frl_sampler_bf16_kernel(const KArgs a) {
           float x0h = (xt - c1 * eps) / c0;                         // continuous_ddpm.py:165
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * x0h + c3 * xt;                                  // :173
-          xn += c5 * zr[r];                                         // :174
+          xn += c5 * z;                                             // :174
         } else if (a.mode == MODE_CDDPM_DDIM) {
           float x0h = (xt - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
@@ -383,6 +375,10 @@ frl_sampler_bf16_kernel(const KArgs a) {
       if (valid && ai < a.A) a.x0[chain * a.A + ai] = xs[r];
     });
   }
+#ifdef FRL_BF_EXP_TIMING
+  FRL_TMARK(5)
+  if (blockIdx.x == 0 && tid == 0) for (int k = 0; k < 6; ++k) a.x0[k] = (float)tsec[k];
+#endif
   // the stream runs three chunks ahead: drain the prefetches before the wave ends
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -394,7 +390,7 @@ static int launch_inst_bf(const KArgs& a, int grid, size_t lds, hipStream_t stre
   auto kern = frl_sampler_bf16_kernel<ACT, NRX, CKS>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
@@ -402,11 +398,8 @@ static int launch_inst_bf(const KArgs& a, int grid, size_t lds, hipStream_t stre
 
 template <int ACT>
 static int launch_act_bf(const KArgs& a, int grid, size_t lds, hipStream_t stream) {
-  if (a.bf_nxk == 1 && a.bf_nck <= 2) return launch_inst_bf<ACT, 8, 2>(a, grid, lds, stream);
-  if (a.bf_nck <= 8) {
-    if (a.bf_nxk == 1) { set_error("internal: bf16 wide instantiation expects 2 x k-steps"); return FRL_EINVAL; }
-    return launch_inst_bf<ACT, 16, 8>(a, grid, lds, stream);
-  }
+  if (a.bf_nxk == 1 && a.bf_cks == 2) return launch_inst_bf<ACT, 8, 2>(a, grid, lds, stream);
+  if (a.bf_nxk == 2 && a.bf_cks == 8) return launch_inst_bf<ACT, 16, 8>(a, grid, lds, stream);
   set_error("bf16 kernel: x_dim %d / cond_dim %d outside the compiled operand budgets (x_dim <= 32, cond_dim <= 128)", a.A, a.C);
   return FRL_EUNSUPPORTED;
 }
@@ -420,7 +413,7 @@ int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-  const long long ntiles = (a.B + 127) / 128;
+  const long long ntiles = (a.B + 255) / 256;
   const int grid = (int)(ntiles < ncu ? ntiles : ncu);
   const size_t lds = bf16_lds_bytes(a.T, a.L);
   if (lds > 160 * 1024) { set_error("bf16 kernel: steps=%d needs %zu B of LDS (> 160 KiB)", a.T, lds); return FRL_EUNSUPPORTED; }
