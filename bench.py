@@ -45,9 +45,9 @@ WORKLOADS = {
                       "T=20, clip +-1, 8192 states x 64 particles/GPU)", kind="cddpm",
                  A=17, S=376, T=20, B=8192 * 64, particles=64, hidden=[256, 256, 256], act="mish", temb="learnable_fourier",
                  schedule="cosine", clip=True, x_min=-1.0, x_max=1.0, cond_embed=True),
-    # cfg5 (f32 here; BASELINE names a bf16 variant): forward with history + chain VJP + (N>1) one all-reduce of the grads
+    # cfg5 (--dtype bf16 = the variant BASELINE names; f32 = the bit-faithful one): forward with history + chain VJP + (N>1) one all-reduce of the grads
     "cfg5": dict(desc="DQL backprop-through-chain VJP (cfg2 shapes: obs 11, act 3, 256x3 mish, vp, T=5, clip +-1, B=262144/GPU), "
-                      "forward+backward, f32", kind="ddpm", A=3, S=11, T=5, B=262144, particles=1, hidden=[256, 256, 256],
+                      "forward+backward", kind="ddpm", A=3, S=11, T=5, B=262144, particles=1, hidden=[256, 256, 256],
                  act="mish", temb="positional", schedule="vp", clip=True, x_min=-1.0, x_max=1.0, cond_embed=False, vjp=True),
 }
 
@@ -93,22 +93,24 @@ def sample(model, w, xT, cond, noise):
 
 def vjp_step(model, w, xT, cond, noise, g):
     """One DQL actor-update worth of sampler work: forward keeping history[0], then the chain VJP."""
-    _, x0, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True)
-    grads, _ = model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False)
+    cd = w.get("dtype", "f32")
+    _, x0, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd)
+    grads, _ = model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
     return x0, grads
 
 
 def vjp_only_ms(model, w, xT, cond, noise, g, iters):
     """Average duration of the backward call alone (frl_sampler_bwd: prepare + sweep + dW kernels, plus the host's
     O(T D^2) time-branch autograd), events on the launch stream."""
-    _, _, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True)
+    cd = w.get("dtype", "f32")
+    _, _, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd)
     for _ in range(2):
-        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False)
+        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(xT.device)
     e0.record()
     for _ in range(iters):
-        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False)
+        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
     e1.record()
     torch.cuda.synchronize(xT.device)
     return e0.elapsed_time(e1) / iters
@@ -259,8 +261,6 @@ def main():
     if args.batch > 0:
         w["B"] = args.batch
     w["dtype"] = args.dtype
-    if args.dtype == "bf16" and w.get("vjp"):
-        raise SystemExit("the chain VJP has no bf16 kernel yet")
     if args.act:
         w["act"] = args.act
     if args.layers > 0:
@@ -320,12 +320,14 @@ def main():
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
             b_ms = vjp_only_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
-            kname = "frl_sampler_rs_kernel (no history) + frl_sampler_bwd call (frl_bwd_sweep_kernel + frl_bwd_dw_kernel)"
+            kname = ("frl_sampler_bf16_kernel (no history) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel + frl_bwd_dw_bf16_kernel)"
+                     if args.dtype == "bf16" else
+                     "frl_sampler_rs_kernel (no history) + frl_sampler_bwd call (frl_bwd_sweep_kernel + frl_bwd_dw_kernel)")
             flops_exec = 4.0 * flops_exec
             flops_alg, k_ms = 3.0 * flops_alg, k_ms + b_ms
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        if args.dtype == "bf16":
+        if args.dtype == "bf16" and not vjp:
             kname = "frl_sampler_bf16_kernel"
         out = {
             "metric": "action samples/sec x T steps (chain-steps/s), fused sampler",

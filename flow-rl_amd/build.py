@@ -25,9 +25,10 @@ ARCH = "gfx950"
 # (source, object stem, extra defines); the register-streamed sampler is one translation unit per activation
 SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []), ("sampler_g32.hip", "sampler_g32", []),
            ("cond_embed.hip", "cond_embed", []), ("sampler_bwd.hip", "sampler_bwd", []),
-           ("sampler_bf16.hip", "sampler_bf16", ["-fno-slp-vectorize"])] + \
+           ("sampler_bf16.hip", "sampler_bf16", ["-fno-slp-vectorize"]),
+           ("sampler_bwd_bf16.hip", "sampler_bwd_bf16", ["-fno-slp-vectorize"])] + \
           [("sampler_rs.hip", f"sampler_rs_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(6)]
-HEADERS = [CSRC / "frl_internal.h", CSRC / "frl_device.h", ROOT / "include" / "flowrl_hip.h"]
+HEADERS = [CSRC / "frl_internal.h", CSRC / "frl_device.h", CSRC / "frl_bf16.h", ROOT / "include" / "flowrl_hip.h"]
 FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++17", "-Wno-unused-value",
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 

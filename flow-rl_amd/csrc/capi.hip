@@ -232,6 +232,13 @@ static int validate_bwd(const FrlDesc* d) {
   if (rc != FRL_OK) return rc;
   Plan pl;
   plan_from_desc(*d, pl);
+  if (d->dtype == FRL_DTYPE_BF16) {
+    // bf16-MFMA VJP (csrc/sampler_bwd_bf16.hip): the narrow instantiation of the bf16 forward kernel
+    if (pl.A > 16 || pl.C > 32 || pl.A + pl.C > 32) { set_error("bf16 VJP: x_dim <= 16 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
+    if (d->cond_embed) { set_error("bf16 VJP: cond_embedding backward not built"); return FRL_EUNSUPPORTED; }
+    if (d->act != FRL_ACT_MISH && d->act != FRL_ACT_SILU && d->act != FRL_ACT_RELU) { set_error("bf16 VJP: activation %d has no backward kernel (mish / silu / relu)", d->act); return FRL_EUNSUPPORTED; }
+    return FRL_OK;
+  }
   if (pl.H != 256 || pl.TR != 32) { set_error("VJP: only the 256-wide (32x32x2) geometry has a backward kernel"); return FRL_EUNSUPPORTED; }
   if (pl.AR > 4 || pl.CK > 12 || pl.A + pl.C > 32) { set_error("VJP: x_dim <= 8 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
   if (d->cond_embed) { set_error("VJP: cond_embedding backward not built"); return FRL_EUNSUPPORTED; }
@@ -241,6 +248,11 @@ static int validate_bwd(const FrlDesc* d) {
 
 size_t frl_bwd_workspace_bytes(const FrlDesc* desc) {
   if (validate_bwd(desc) != FRL_OK) return 0;
+  if (desc->dtype == FRL_DTYPE_BF16) {
+    BwdPlan16 bp;
+    bwd16_plan_from_desc(*desc, bp);
+    return bp.total_floats * sizeof(float);
+  }
   BwdPlan bp;
   bwd_plan_from_desc(*desc, bp);
   return bp.total_floats * sizeof(float);
@@ -252,10 +264,14 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
   BwdPlan bp;
-  bwd_plan_from_desc(*desc, bp);
+  BwdPlan16 bp16;
+  const bool bf16 = desc->dtype == FRL_DTYPE_BF16;
+  if (bf16) { bwd16_plan_from_desc(*desc, bp16); bp.f = bp16.f; bp.total_floats = bp16.total_floats; }
+  else bwd_plan_from_desc(*desc, bp);
   const Plan& pl = bp.f;
   if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
   if (workspace_bytes < bp.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B", workspace_bytes, bp.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  if (bf16 && bp16.off_img_b != pl.off_bf16 + (size_t)pl.bf_ns * (BF_CHUNK_BYTES / 4)) { set_error("bf16 VJP: stream images not contiguous"); return FRL_EINVAL; }
   if (pl.B == 0) return FRL_OK;
   if (bufs->xt_hist == nullptr || bufs->g_x0 == nullptr || bufs->grad_tb == nullptr) { set_error("bufs.xt_hist / g_x0 / grad_tb is NULL"); return FRL_EINVAL; }
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
@@ -268,7 +284,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   rc = frl_sampler_prepare(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream);
   if (rc != FRL_OK) return rc;
   float* ws = (float*)workspace;
-  rc = launch_prepare_bwd(*params, bp, ws, stream);
+  rc = bf16 ? launch_prepare_bwd_bf16(*params, bp16, ws, stream) : launch_prepare_bwd(*params, bp, ws, stream);
   if (rc != FRL_OK) return rc;
   // gradients are accumulated with float atomics: zero them first
   const int Dp = pl.Dp;
@@ -286,7 +302,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   memset(&b, 0, sizeof(b));
   KArgs& a = b.k;
   a.cond = bufs->cond;
-  for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; b.wt[l - 1] = ws + bp.off_wt[l - 1]; }
+  for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; b.wt[l - 1] = bf16 ? nullptr : ws + bp.off_wt[l - 1]; }
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
@@ -294,13 +310,19 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
   b.xt_hist = bufs->xt_hist; b.g_x0 = bufs->g_x0; b.g_xT = bufs->g_xT;
-  b.ws_wlt = ws + bp.off_wlt; b.ws_w0xq = ws + bp.off_w0xq;
-  b.hd = ws + bp.off_hd; b.ad = ws + bp.off_ad; b.gd = ws + bp.off_gd; b.ge = ws + bp.off_ge;
+  if (bf16) {
+    a.ws_bf16 = ws + pl.off_bf16;
+    a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
+    b.hd = ws + bp16.off_hd; b.ad = ws + bp16.off_ad; b.gd = ws + bp16.off_gd; b.ge = ws + bp16.off_ge;
+  } else {
+    b.ws_wlt = ws + bp.off_wlt; b.ws_w0xq = ws + bp.off_w0xq;
+    b.hd = ws + bp.off_hd; b.ad = ws + bp.off_ad; b.gd = ws + bp.off_gd; b.ge = ws + bp.off_ge;
+  }
   for (int l = 0; l <= pl.L; ++l) { b.grad_kernel[l] = bufs->grad_kernel[l]; b.grad_bias[l] = bufs->grad_bias[l]; }
   b.grad_tb = bufs->grad_tb;
   b.Dp = Dp;
-  b.n_ts = bp.n_ts;
-  return launch_sampler_bwd(*desc, b, stream);
+  b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
+  return bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stream);
 }
 
 int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream) {

@@ -176,6 +176,38 @@ struct BArgs {
   long long n_ts;
 };
 
+// ---- backward, bf16-MFMA variant (csrc/sampler_bwd_bf16.hip) -------------------------------------------------
+// Workspace = the forward plan with its bf16 weight stream image, DIRECTLY followed by the backward stream image
+// (same chunk format: W_L^T, transposed hidden kernels top-down, Dense_0's x rows), so that the sweep cycles through
+// 2 * bf_ns chunks per step; then the stash, packed bf16 in the B-operand layout of the sweep
+// ([16 k-step pieces][64 lanes][8 bf16] = 16 KB per (wave-tile, step, layer)):
+//   Hd = bf16(act(z_l)), Ad = bf16(act'(z_l)), Gd = bf16(dL/dz_l), and Ge = bf16(dL/deps) (one 1 KB piece).
+// Wave tiles are counted per 256-chain workgroup tile (8 each), so that every wave of the sweep owns a stash slot.
+struct BwdPlan16 {
+  Plan f;
+  long long n_wt, n_ts;
+  size_t off_img_b, off_hd, off_ad, off_gd, off_ge, total_floats;
+};
+
+inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
+  plan_from_desc(d, b.f);
+  const Plan& p = b.f;
+  b.n_wt = 8 * ((p.B + 255) / 256);
+  b.n_ts = b.n_wt * p.T;
+  size_t o = p.total_floats;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+  b.off_img_b = take((size_t)p.bf_ns * (BF_CHUNK_BYTES / 4));
+  b.off_hd = take((size_t)b.n_ts * p.L * 4096);
+  b.off_ad = take((size_t)b.n_ts * p.L * 4096);
+  b.off_gd = take((size_t)b.n_ts * p.L * 4096);
+  b.off_ge = take((size_t)b.n_ts * 256);
+  b.total_floats = o;
+  return 0;
+}
+
+int launch_prepare_bwd_bf16(const FrlParams& p, const BwdPlan16& bp, float* ws, hipStream_t stream);
+int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& a, hipStream_t stream);
+
 int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
 int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, hipStream_t stream);
 

@@ -25,20 +25,9 @@
 // 32 KB chunks (2 output blocks) by LDS-DMA into a 4-slot ring, three chunks in flight, one s_barrier per chunk,
 // read back with one ds_read_b128 per MFMA.  Plain f32 VALU only: v_pk_*_f32 beside bf16 MFMAs is an anti-lever
 // (measured +8.5 cycles each) — this TU is built with -fno-slp-vectorize so the compiler does not pack either.
-#include "frl_device.h"
+#include "frl_bf16.h"
 
 namespace frl {
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-#define BF_ROWR(r) (((r) & 3) + 8 * ((r) >> 2))
-
-__device__ __forceinline__ unsigned short f2bf(float f) {   // round to nearest even (NaN not expected in weights)
-  unsigned u = __builtin_bit_cast(unsigned, f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 
 // ---- weight stream image ------------------------------------------------------------------------------------
 struct PBfArgs {
@@ -132,22 +121,6 @@ __device__ __forceinline__ u32x4 pack_act(const f32x16& p) {
     o[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
   });
   return o;
-}
-
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-}
-
-__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-template <int OFF>
-__device__ __forceinline__ void dma16_bf(const void* gsrc, void* lds_dst) {
-  // 64 lanes x 16 B: per-lane global source, LDS destination = wave-uniform base + lane * 16; the instruction's
-  // immediate offset OFF applies to both sides (pieces are 1 KB apart in the image and in the ring alike)
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
 }
 
 // One Dense layer, output-block-major: for each of the NOB output blocks, NK MFMAs into one accumulator; the

@@ -288,7 +288,7 @@ def time_branch_vjp(network, params: Dict, tvals: torch.Tensor, grad_tb: torch.T
 def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int, xt_hist: torch.Tensor,
                     condition: Optional[torch.Tensor], g_x0: torch.Tensor, sched: Dict[str, torch.Tensor],
                     tvals: torch.Tensor, clip_sampler: bool, x_min, x_max, particles: Optional[int] = None,
-                    want_gxT: bool = True):
+                    want_gxT: bool = True, compute_dtype: str = "f32"):
     """dL/dparams (Flax-layout tree) and dL/dxT of one sampler call, given its history[0] and dL/dx0.
     The O(B) work (recompute + backward sweep + weight-gradient GEMMs) is libflowrl_hip's frl_sampler_bwd; the
     batch-invariant time branch is finished here from the kernel's dL/dtb (see :func:`time_branch_vjp`)."""
@@ -300,7 +300,8 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
     lead = tuple(g_x0.shape[:-1])
     desc, fparams, fs, keep, B, cond2d = _marshal(
         network, params, kind=kind, solver=solver, steps=steps, xT=g_x0, condition=condition, sched=sched,
-        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles)
+        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles,
+        compute_dtype=compute_dtype)
     if xt_hist.numel() != steps * B * A:
         raise ValueError(f"xt_hist has {xt_hist.numel()} elements, expected (T, ..., A) = {steps * B * A}")
     xt_hist = _f32c(xt_hist.reshape(steps, B, A), device, "xt_hist")

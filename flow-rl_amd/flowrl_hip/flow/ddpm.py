@@ -88,11 +88,13 @@ class DDPM:
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: str = "ddpm", params: Optional[Dict] = None, *, particles: Optional[int] = None,
-                   want_gxT: bool = True) -> Tuple[Dict, Optional[torch.Tensor]]:
+                   want_gxT: bool = True, compute_dtype: str = "f32") -> Tuple[Dict, Optional[torch.Tensor]]:
         """VJP of :meth:`sample` w.r.t. the parameter tree and xT: what ``jax.grad`` through
         ``actor.sample(..., training=True, params=p)`` computes in the DQL actor update (dql.py:93-123 through
         ddpm.py:186-219).  ``xt_hist`` = history[0] of the forward call (``sample(..., history=True)``),
-        ``g_x0`` = dL/dx0.  Returns (grads in the layout of ``params``, dL/dxT)."""
+        ``g_x0`` = dL/dx0.  Returns (grads in the layout of ``params``, dL/dxT).  ``compute_dtype`` = "bf16": the
+        bf16-MFMA VJP (bf16 operands, f32 accumulation; stated tolerance, tests/test_gpu_vjp_bf16.py) — pair it with a
+        forward call of the same compute_dtype."""
         if solver not in SUPPORTED_SOLVERS:
             raise NotImplementedError(f"Unsupported solver {solver} for {type(self)}")
         p = params if params is not None else self.params
@@ -103,4 +105,4 @@ class DDPM:
             xt_hist=xt_hist, condition=condition, g_x0=g_x0,
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
-            particles=particles, want_gxT=want_gxT)
+            particles=particles, want_gxT=want_gxT, compute_dtype=compute_dtype)

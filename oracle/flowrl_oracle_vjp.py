@@ -77,6 +77,54 @@ def _mlp_bwd(p, cache, gout, n_hidden, act_name, has_output, grads):
     return g
 
 
+# ---- predictor with bf16 operands (emulation of csrc/sampler_bf16.hip + csrc/sampler_bwd_bf16.hip) ------------
+# Every Dense contraction takes operands rounded to bf16 and sums exactly: layer inputs and kernels in the forward
+# (orc._predictor_bf16), and in the backward dL/dz_l = bf16(dL/dh_l * bf16(act'(z_l))), dL/deps and the transposed
+# kernels.  The time slice of Dense_0 (folded into the f32 bias table by the kernel) and all biases stay exact.
+def _pred_fwd_bf16(spec, p, x, tfeat, condition):
+    bf = orc.bf16_round
+    act = orc.get_activation(spec.activation)
+    A, Dp = x.shape[-1], tfeat.shape[-1]
+    n = len(spec.hidden_dims)
+    W0 = p["Dense_0"]["kernel"]
+    parts = [bf(x), tfeat] + ([bf(condition)] if condition is not None else [])
+    xin = np.concatenate(parts, axis=-1)
+    W0b = np.concatenate([bf(W0[:A]), W0[A:A + Dp], bf(W0[A + Dp:])], axis=0)
+    cache = []
+    z = xin @ W0b + p["Dense_0"]["bias"]
+    cache.append((xin, z, W0b))
+    for i in range(1, n):
+        hb = bf(act(z))
+        Wb = bf(p[f"Dense_{i}"]["kernel"])
+        z = hb @ Wb + p[f"Dense_{i}"]["bias"]
+        cache.append((hb, z, Wb))
+    hb = bf(act(z))
+    Wb = bf(p[f"Dense_{n}"]["kernel"])
+    cache.append((hb, None, Wb))
+    return hb @ Wb + p[f"Dense_{n}"]["bias"], cache
+
+
+def _pred_bwd_bf16(spec, cache, gout, grads):
+    bf = orc.bf16_round
+    n = len(spec.hidden_dims)
+
+    def acc(i, xin, g):
+        d = grads.setdefault(f"Dense_{i}", {"kernel": 0.0, "bias": 0.0})
+        d["kernel"] = d["kernel"] + xin.reshape(-1, xin.shape[-1]).T @ g.reshape(-1, g.shape[-1])
+        d["bias"] = d["bias"] + g.reshape(-1, g.shape[-1]).sum(0)
+
+    g = bf(gout)
+    xin, _, Wb = cache[n]
+    acc(n, xin, g)
+    g = g @ Wb.T
+    for i in reversed(range(n)):
+        xin, z, Wb = cache[i]
+        g = bf(g * bf(act_grad(spec.activation, z)))
+        acc(i, xin, g)
+        g = g @ Wb.T
+    return g
+
+
 def backbone_fwd(spec: orc.BackboneSpec, params: Dict, x, time, condition):
     """DDPMBackbone.__call__ (ddpm.py:83-95) keeping what the backward needs."""
     c = {"time_in": time}
@@ -90,16 +138,22 @@ def backbone_fwd(spec: orc.BackboneSpec, params: Dict, x, time, condition):
         tfeat = time
     if spec.cond_hidden is not None:
         condition, c["cmlp"] = _mlp_fwd(params["cond_embedding"], condition, len(spec.cond_hidden), spec.activation, False)
+    c["dims"] = (x.shape[-1], tfeat.shape[-1])
+    if spec.bf16_operands:
+        out, c["pred"] = _pred_fwd_bf16(spec, params[spec.predictor_name], x, tfeat, condition)
+        return out, c
     parts = [x, tfeat] + ([condition] if condition is not None else [])
     inputs = np.concatenate(parts, axis=-1)
     out, c["pred"] = _mlp_fwd(params[spec.predictor_name], inputs, len(spec.hidden_dims), spec.activation, True)
-    c["dims"] = (x.shape[-1], tfeat.shape[-1])
     return out, c
 
 
 def backbone_bwd(spec: orc.BackboneSpec, params: Dict, c, gout, grads: Dict):
-    gin = _mlp_bwd(params[spec.predictor_name], c["pred"], gout, len(spec.hidden_dims), spec.activation, True,
-                   grads.setdefault(spec.predictor_name, {}))
+    if spec.bf16_operands:
+        gin = _pred_bwd_bf16(spec, c["pred"], gout, grads.setdefault(spec.predictor_name, {}))
+    else:
+        gin = _mlp_bwd(params[spec.predictor_name], c["pred"], gout, len(spec.hidden_dims), spec.activation, True,
+                       grads.setdefault(spec.predictor_name, {}))
     A, Dp = c["dims"]
     gx, gt, gc = gin[..., :A], gin[..., A:A + Dp], gin[..., A + Dp:]
     if spec.cond_hidden is not None:
@@ -122,8 +176,11 @@ def backbone_bwd(spec: orc.BackboneSpec, params: Dict, c, gout, grads: Dict):
 
 # ---- chain VJP --------------------------------------------------------------------------------------------
 def ddpm_sample_vjp(spec: orc.BackboneSpec, params: Dict, tables, xT, condition, noise, g, *, steps: int,
-                    solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None):
-    """d sum(g * x0) / d params and / d xT for DDPM.sample (ddpm.py:173-221).  float64 throughout."""
+                    solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None, xt_hist=None):
+    """d sum(g * x0) / d params and / d xT for DDPM.sample (ddpm.py:173-221).  float64 throughout.
+    ``xt_hist`` (T, ..., A), optional: take the input of iteration j from it instead of from the recomputed chain —
+    the product's VJP works from the forward call's history[0] the same way, so a reduced-precision variant can be
+    checked on identical chain states."""
     dt = np.float64
     params = orc.cast_tree(params, dt)
     betas, alphas, alpha_hats, postvars = [np.asarray(a, dtype=dt) for a in tables]
@@ -132,6 +189,8 @@ def ddpm_sample_vjp(spec: orc.BackboneSpec, params: Dict, tables, xT, condition,
     noise = np.asarray(noise, dt)
     fw = []
     for j, t in enumerate(range(steps, 0, -1)):
+        if xt_hist is not None:
+            xt = np.asarray(xt_hist[j], dt)
         tin = np.full((*xt.shape[:-1], 1), float(t), dtype=dt)
         eps, cache = backbone_fwd(spec, params, xt, tin, cond)
         ah, ah1, al = alpha_hats[t], alpha_hats[t - 1], alphas[t]
