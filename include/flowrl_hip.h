@@ -62,7 +62,7 @@ extern "C" {
 #define FRL_ACT_ELU 5       /* jax.nn.elu   (activation.py:11) */
 
 #define FRL_DTYPE_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the bit-faithful path */
-#define FRL_DTYPE_BF16 1 /* reserved: bf16 MFMA, f32 accumulate / chain state */
+#define FRL_DTYPE_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16) operands, f32 accumulate / activations / chain state: stated tolerance */
 
 /* Static description of one sampler call — the analogue of the reference's jit static_argnames
  * plus the pytree_node=False fields of DDPM / ContinuousDDPM / ContinuousNormalizingFlow
@@ -154,7 +154,8 @@ int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
  * Given the forward's history xt_hist (want_history = 1) and the cotangent g_x0 = dL/dx0, computes dL/d(params) of the
  * predictor MLP and dL/dxT.  The batch-invariant time branch is differentiated by the caller from grad_tb
  * (dL/d(tb), tb[j] = bias_0 + tfeat[j] @ kernel_0[A:A+D']): its gradients are O(T * D^2) work.
- * This build: DDPM / ContinuousDDPM / CNF update rules, 256-wide predictor, mish / silu / relu, x_dim <= 8,
+ * This build: DDPM / ContinuousDDPM / CNF update rules, 256-wide predictor, mish / silu / relu, x_dim <= 8
+ * (FRL_DTYPE_F32) or <= 16 (FRL_DTYPE_BF16: bf16 operands in every contraction, f32 accumulation),
  * x_dim + cond_dim <= 32, no cond_embedding; everything else returns FRL_EUNSUPPORTED. */
 typedef struct FrlBwdBufs {
   const float* xt_hist; /* (T, B, A) history[0] of the forward call                                     */
