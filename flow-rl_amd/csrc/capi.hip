@@ -25,8 +25,13 @@ static int validate_desc(const FrlDesc* d) {
   if (d->kind == FRL_KIND_CNF) {
     if (d->solver != FRL_SOLVER_EULER) { set_error("CNF sampler supports solver EULER only (cnf.py:92-111)"); return FRL_EINVAL; }
   } else if (d->solver != FRL_SOLVER_DDPM && d->solver != FRL_SOLVER_DDIM) {
-    set_error("solver %d not supported for kind %d (ddpm / ddim only; dpm2 and dpm++2m fall back to the host path)", d->solver, d->kind);
-    return d->solver == FRL_SOLVER_EULER ? FRL_EINVAL : FRL_EUNSUPPORTED;
+    const bool dpm = d->solver == FRL_SOLVER_DPM2 || d->solver == FRL_SOLVER_DPMPP2M;
+    if (!dpm || d->kind != FRL_KIND_CDDPM) {   // ddpm.py:16-18: the discrete sampler knows ddim / ddpm only
+      set_error("solver %d invalid for kind %d (DDPM: ddpm / ddim; ContinuousDDPM: ddpm / ddim / dpm2 / dpm++2m)", d->solver, d->kind);
+      return FRL_EINVAL;
+    }
+    if (d->dtype != FRL_DTYPE_F32) { set_error("solvers dpm2 / dpm++2m run in the f32 kernel only"); return FRL_EUNSUPPORTED; }
+    if (d->solver == FRL_SOLVER_DPM2 && d->steps > 128) { set_error("dpm2: steps %d > 128 (two table rows per step)", d->steps); return FRL_EUNSUPPORTED; }
   }
   if (d->steps < 1 || d->steps > 256) { set_error("desc.steps %d outside [1, 256]", d->steps); return FRL_EINVAL; }
   if (d->n_states < 0 || d->particles < 1) { set_error("n_states %lld / particles %d invalid", (long long)d->n_states, d->particles); return FRL_EINVAL; }
@@ -102,7 +107,8 @@ size_t frl_workspace_bytes(const FrlDesc* desc) {
 
 double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
   if (desc == nullptr || desc->n_hidden < 1 || desc->n_hidden > FRL_MAX_HIDDEN) return 0.0;
-  const double B = (double)desc->n_states * desc->particles, T = desc->steps;
+  const double B = (double)desc->n_states * desc->particles;
+  const double T = (desc->solver == FRL_SOLVER_DPM2 ? 2.0 : 1.0) * desc->steps;   // network evaluations per chain
   const int A = desc->x_dim, C = desc->cond_dim;
   const int Dp = desc->time_embed == FRL_TEMB_NONE ? 1 : desc->time_dim;
   double macs = (double)(A + Dp + C) * desc->hidden[0];
@@ -145,6 +151,8 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
     if (s.alphas == nullptr || s.alpha_hats == nullptr) { set_error("sched.alphas / alpha_hats is NULL"); return FRL_EINVAL; }
     if (desc->kind == FRL_KIND_DDPM && desc->solver == FRL_SOLVER_DDPM && s.postvars == nullptr) { set_error("sched.postvars is NULL"); return FRL_EINVAL; }
     if (desc->kind == FRL_KIND_CDDPM && (s.ts == nullptr || s.betas == nullptr)) { set_error("sched.ts / betas is NULL"); return FRL_EINVAL; }
+    if (desc->solver == FRL_SOLVER_DPM2 && (s.mid_ts == nullptr || s.mid_alphas == nullptr || s.mid_sigmas == nullptr)) {
+      set_error("sched.mid_ts / mid_alphas / mid_sigmas is NULL (dpm2 evaluates the schedule at the interval midpoints)"); return FRL_EINVAL; }
   }
   PArgs pa;
   pa.p = *params;
@@ -198,6 +206,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
+  a.NE = pl.NE;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
@@ -208,7 +217,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   }
   // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)
   static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
-  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU)
+  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER)
     return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
   switch (desc->act) {
     case FRL_ACT_MISH: return launch_sampler_rs_act<FRL_ACT_MISH>(a, (hipStream_t)hip_stream);
@@ -232,6 +241,7 @@ static int validate_bwd(const FrlDesc* d) {
   if (rc != FRL_OK) return rc;
   Plan pl;
   plan_from_desc(*d, pl);
+  if (pl.mode > MODE_CNF_EULER) { set_error("VJP: solvers dpm2 / dpm++2m have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->dtype == FRL_DTYPE_BF16) {
     // bf16-MFMA VJP (csrc/sampler_bwd_bf16.hip): the narrow instantiation of the bf16 forward kernel
     if (pl.A > 16 || pl.C > 32 || pl.A + pl.C > 32) { set_error("bf16 VJP: x_dim <= 16 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
@@ -306,6 +316,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
+  a.NE = pl.NE;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;

@@ -31,6 +31,8 @@ enum Mode : int {
   MODE_CDDPM_DDPM = 2,  // continuous_ddpm.py:165-174
   MODE_CDDPM_DDIM = 3,  // continuous_ddpm.py:165-166,176-177
   MODE_CNF_EULER = 4,   // cnf.py:108-110
+  MODE_CDDPM_DPMPP2M = 5,  // continuous_ddpm.py:198-212 (carries the previous x0_hat in registers)
+  MODE_CDDPM_DPM2 = 6,     // continuous_ddpm.py:179-196 (two network evaluations per step: NE = 2 T)
 };
 
 // FRL_GEO=16 selects the 16x16x4 geometry for 256-wide nets too (A/B measurements)
@@ -43,6 +45,7 @@ inline bool prefer_tr16() {
 struct Plan {
   int A, C, D, Dp;      // action dim, cond dim, time_dim, D' (= D or 1) rows of Dense_0 taken by time
   int H, L, T;
+  int NE;               // network evaluations per chain = rows of the coefficient / bias tables (T; 2 T for dpm2)
   int TR, KS, NR;       // geometry: MFMA tile rows (32: 32x32x2, 16: 16x16x4), k per MFMA, accumulators per block
   int XR;               // layer-0 x rows in the packed image: 4 KS ceil(A / 4KS) (row a = ROWR(r) + 4 s)
   int AR;               // x registers per lane = XR / KS
@@ -82,12 +85,15 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.NS = p.n_l0 + 8 * (p.L - 1) + 1;
   p.B = (long long)d.n_states * d.particles;
   if (d.kind == FRL_KIND_DDPM) p.mode = (d.solver == FRL_SOLVER_DDIM) ? MODE_DDPM_DDIM : MODE_DDPM_DDPM;
-  else if (d.kind == FRL_KIND_CDDPM) p.mode = (d.solver == FRL_SOLVER_DDIM) ? MODE_CDDPM_DDIM : MODE_CDDPM_DDPM;
+  else if (d.kind == FRL_KIND_CDDPM)
+    p.mode = (d.solver == FRL_SOLVER_DDIM) ? MODE_CDDPM_DDIM : (d.solver == FRL_SOLVER_DPM2) ? MODE_CDDPM_DPM2
+           : (d.solver == FRL_SOLVER_DPMPP2M) ? MODE_CDDPM_DPMPP2M : MODE_CDDPM_DDPM;
   else p.mode = MODE_CNF_EULER;
+  p.NE = (p.mode == MODE_CDDPM_DPM2) ? 2 * p.T : p.T;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };  // 256-B aligned pieces
-  p.off_coef = take((size_t)p.T * COEF_STRIDE);
-  p.off_tb = take((size_t)p.T * p.H);
+  p.off_coef = take((size_t)p.NE * COEF_STRIDE);
+  p.off_tb = take((size_t)p.NE * p.H);
   p.w0p_rows = (size_t)(p.merged ? SLAB_ROWS : p.XR + (p.n_l0 - 1) * SLAB_ROWS);
   if (p.w0p_rows < (size_t)p.K0p) p.w0p_rows = (size_t)p.K0p;
   p.off_w0p = take(p.w0p_rows * p.H);
@@ -114,6 +120,7 @@ struct KArgs {
   const float* ws_coef; const float* ws_tb; const float* ws_w0p; const float* ws_wlp; const float* ws_wlq; const float* ws_blp;
   long long B;
   int particles, A, C, T, L, H, TR, mode, clip;
+  int NE;                                 // network evaluations per chain (table rows); = T except dpm2
   int w0p_bytes;
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;

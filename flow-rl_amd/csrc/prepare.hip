@@ -25,7 +25,7 @@ __device__ __forceinline__ float mish_exact(float x) {
 }
 
 __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
-  extern __shared__ float sh[];  // 3 * T * Dmax floats
+  extern __shared__ float sh[];  // 3 * NE * Dmax floats
   const Plan& pl = a.plan;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int T = pl.T, H = pl.H, A = pl.A, C = pl.C, D = pl.D, Dp = pl.Dp;
@@ -36,15 +36,17 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   float* wlp = ws + pl.off_wlp;
   float* wlq = ws + pl.off_wlq;
   float* blp = ws + pl.off_blp;
-  float* temb = sh;                 // [T][D]
-  float* h1 = sh + (size_t)T * (D > 0 ? D : 1);
-  float* h2 = h1 + (size_t)T * (D > 0 ? D : 1);
-  __shared__ float tvals[256];      // time input of loop iteration j (T <= 256 checked on host)
+  float* temb = sh;                 // [NE][D]
+  float* h1 = sh + (size_t)pl.NE * (D > 0 ? D : 1);
+  float* h2 = h1 + (size_t)pl.NE * (D > 0 ? D : 1);
+  __shared__ float tvals[256];      // time input of network evaluation e (NE <= 256 checked on host)
 
-  // ---- coefficients + time values -------------------------------------------------------------
-  for (int j = tid; j < T; j += nt) {
+  // ---- coefficients + time values, one row per network evaluation -----------------------------------
+  const int NE = pl.NE;
+  for (int e = tid; e < NE; e += nt) {
     float c[COEF_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
     float tv;
+    const int j = (pl.mode == MODE_CDDPM_DPM2) ? e >> 1 : e;     // loop iteration of the reference's scan
     if (pl.mode == MODE_CNF_EULER) {
       tv = (float)j / (float)T;              // step2t(arange(steps)), cnf.py:80-83,139
       c[0] = (float)T;                       // x_next = xt + vel / steps, cnf.py:108
@@ -73,14 +75,42 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
           c[2] = sqrtf(ah1) * be / (1.0f - ah);            // mean_coef1
           c[3] = sqrtf(al) * (1.0f - ah1) / (1.0f - ah);   // mean_coef2
           c[5] = (t > 1 ? 1.0f : 0.0f) * sqrtf(be);
-        } else {
+        } else if (pl.mode == MODE_CDDPM_DDIM) {
           c[2] = sqrtf(ah1);
           c[3] = sqrtf(1.0f - ah1);
+        } else if (pl.mode == MODE_CDDPM_DPM2) {
+          // continuous_ddpm.py:179-196.  Evaluation 2j: eps at (xt, ts[t]) -> x_s = alpha_s x0_hat + sigma_s eps;
+          // evaluation 2j+1: eps_s at (x_s, midpoint) -> xt_1 = sqrt(ah1) x0_hat_corrected + sqrt(1 - ah1) eps_s,
+          // the corrected x0_hat taken from the ORIGINAL xt.  Both have the shape  c2 * x0_hat + c3 * eps.
+          if ((e & 1) == 0) {
+            c[2] = a.s.mid_alphas[t - 1];
+            c[3] = a.s.mid_sigmas[t - 1];
+          } else {
+            tv = a.s.mid_ts[t - 1];
+            c[2] = sqrtf(ah1);
+            c[3] = sqrtf(1.0f - ah1);
+            c[6] = 1.0f;                                    // second evaluation of the step
+          }
+        } else {
+          // DPM-Solver++(2M), continuous_ddpm.py:141-142,198-212.  All of h, prev_h, r are batch-invariant:
+          //   d = c4 * x0_hat - c5 * prev_x0_hat;   xt_1 = c2 * xt - c3 * d
+          auto lam = [&](int k) {
+            const float v = a.s.alpha_hats[k];
+            return logf(sqrtf(v) / sqrtf(fmaxf(1.0f - v, 1e-12f)));
+          };
+          const float h = lam(t - 1) - lam(t);
+          const float prev_h = (j == 0) ? 0.0f : lam(t) - lam(t + 1);    // h of the previous iteration (carry init 0)
+          const float r = prev_h / fmaxf(h, 1e-8f);
+          const bool second = prev_h > 1e-8f;
+          c[2] = sqrtf(1.0f - ah1) / sqrtf(1.0f - ah);      // sigma_next / sigma_curr
+          c[3] = sqrtf(ah1) * (float)expm1((double)-h);     // alpha_next * expm1(-h)
+          c[4] = second ? 1.0f + 0.5f / r : 1.0f;
+          c[5] = second ? 0.5f / r : 0.0f;
         }
       }
     }
-    tvals[j] = tv;
-    for (int k = 0; k < COEF_STRIDE; ++k) coef[j * COEF_STRIDE + k] = c[k];
+    tvals[e] = tv;
+    for (int k = 0; k < COEF_STRIDE; ++k) coef[e * COEF_STRIDE + k] = c[k];
   }
   __syncthreads();
 
@@ -89,14 +119,14 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
 
   if (a.time_embed == FRL_TEMB_NONE) {
     // raw scalar time is input column A of Dense_0 (cnf.py:38-41)
-    for (int idx = tid; idx < T * H; idx += nt) {
+    for (int idx = tid; idx < NE * H; idx += nt) {
       const int j = idx / H, f = idx - j * H;
       tb[idx] = fmaf(tvals[j], W0[(size_t)A * H + f], b0[f]);
     }
   } else {
     const int half = D / 2;
     // ---- embedding ------------------------------------------------------------------------------
-    for (int idx = tid; idx < T * D; idx += nt) {
+    for (int idx = tid; idx < NE * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       const int dd = (d < half) ? d : d - half;
       float arg;
@@ -114,7 +144,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
     __syncthreads();
     // ---- MLP_0/Dense_0 + mish ---------------------------------------------------------------------
-    for (int idx = tid; idx < T * D; idx += nt) {
+    for (int idx = tid; idx < NE * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       float acc = 0.0f;
       for (int k = 0; k < D; ++k) acc = fmaf(temb[j * D + k], a.p.tmlp_kernel[0][(size_t)k * D + d], acc);
@@ -122,7 +152,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
     __syncthreads();
     // ---- MLP_0/Dense_1 + mish ---------------------------------------------------------------------
-    for (int idx = tid; idx < T * D; idx += nt) {
+    for (int idx = tid; idx < NE * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       float acc = 0.0f;
       for (int k = 0; k < D; ++k) acc = fmaf(h1[j * D + k], a.p.tmlp_kernel[1][(size_t)k * D + d], acc);
@@ -130,7 +160,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
     __syncthreads();
     // ---- time slice of predictor Dense_0 -> bias table --------------------------------------------
-    for (int idx = tid; idx < T * H; idx += nt) {
+    for (int idx = tid; idx < NE * H; idx += nt) {
       const int j = idx / H, f = idx - j * H;
       float acc = 0.0f;
       for (int k = 0; k < D; ++k) acc = fmaf(h2[j * D + k], W0[(size_t)(A + k) * H + f], acc);
@@ -176,7 +206,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
 
 int launch_prepare(const PArgs& a, hipStream_t stream) {
   const int Dm = a.plan.D > 0 ? a.plan.D : 1;
-  const size_t shbytes = (size_t)3 * a.plan.T * Dm * sizeof(float);
+  const size_t shbytes = (size_t)3 * a.plan.NE * Dm * sizeof(float);
   if (shbytes > 60000) { set_error("prepare: T*time_dim too large (%zu B of LDS)", shbytes); return FRL_EUNSUPPORTED; }
   hipLaunchKernelGGL(frl_prepare_kernel, dim3(1), dim3(256), shbytes, stream, a);
   hipError_t e = hipGetLastError();

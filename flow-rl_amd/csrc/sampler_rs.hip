@@ -57,17 +57,17 @@ frl_sampler_rs_kernel(const KArgs a) {
   const int nw = blockDim.x >> 6;
   const int li = lane % TR, ls = lane / TR;
 
-  float* s_tb = (float*)smem;                         // [T][H]  layer-0 bias table (time slice folded in)
-  float* s_bh = s_tb + a.T * H;                       // [L-1][H] hidden biases
+  float* s_tb = (float*)smem;                         // [NE][H] layer-0 bias table (time slice folded in), one row per network evaluation
+  float* s_bh = s_tb + a.NE * H;                      // [L-1][H] hidden biases
   float* s_bl = s_bh + (a.L - 1) * H;                 // [32]    padded last-layer bias
-  float* s_coef = s_bl + LAST_PAD;                    // [T][8]
-  for (int idx = tid; idx < a.T * H; idx += blockDim.x) s_tb[idx] = a.ws_tb[idx];
+  float* s_coef = s_bl + LAST_PAD;                    // [NE][8]
+  for (int idx = tid; idx < a.NE * H; idx += blockDim.x) s_tb[idx] = a.ws_tb[idx];
   for (int l = 1; l < a.L; ++l) {
     const float* bp = pick_ptr_rs(a.bh, l - 1);
     for (int idx = tid; idx < H; idx += blockDim.x) s_bh[(l - 1) * H + idx] = bp[idx];
   }
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
-  for (int idx = tid; idx < a.T * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
+  for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
   __syncthreads();
 
   // per-lane parts of the weight addresses (bytes)
@@ -142,7 +142,10 @@ frl_sampler_rs_kernel(const KArgs a) {
       cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
     });
 
-    for (int j = 0; j < a.T; ++j) {
+    float aux[NRX];     // dpm++2m: previous x0_hat (scan carry, continuous_ddpm.py:219); dpm2: the step's original xt
+    sfor<NRX>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
+
+    for (int j = 0; j < a.NE; ++j) {   // one iteration per network evaluation (= per sampler step, except dpm2: two)
       // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
       bias_init(P, s_tb + j * H);
       sfor<N0>([&](auto NI) {
@@ -235,8 +238,10 @@ frl_sampler_rs_kernel(const KArgs a) {
         const int ai = G::rowr(r) + 4 * ls;
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
-        if (a.xt_hist != nullptr && in) {
-          const long long o = ((long long)j * a.B + chain) * a.A + ai;
+        const float c6 = s_coef[j * COEF_STRIDE + 6];             // dpm2: 1 on the second evaluation of a step
+        if (a.xt_hist != nullptr && in && c6 == 0.0f) {           // history = (xt, eps_theta) of the step, :217
+          const int jh = (a.mode == MODE_CDDPM_DPM2) ? j >> 1 : j;
+          const long long o = ((long long)jh * a.B + chain) * a.A + ai;
           a.xt_hist[o] = xt;
           a.eps_hist[o] = eps;
         }
@@ -258,6 +263,18 @@ frl_sampler_rs_kernel(const KArgs a) {
           float x0h = (xt - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * x0h + c3 * eps;                                 // :177
+        } else if (a.mode == MODE_CDDPM_DPMPP2M) {
+          float x0h = (xt - c1 * eps) / c0;                         // :165
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          const float d = c4 * x0h - c5 * aux[r];                   // :207-211 (c4 = 1, c5 = 0 on the first-order step)
+          xn = c2 * xt - c3 * d;                                    // :212
+          aux[r] = x0h;                                             // carry, :217
+        } else if (a.mode == MODE_CDDPM_DPM2) {
+          const float xo = (c6 == 0.0f) ? xt : aux[r];              // both x0_hats come from the ORIGINAL xt, :165,:194
+          float x0h = (xo - c1 * eps) / c0;
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * x0h + c3 * eps;                                 // :187 (to the midpoint) / :196 (full step)
+          aux[r] = xo;
         } else {
           xn = xt + eps / c0;                                       // cnf.py:108
           if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
@@ -298,8 +315,8 @@ static int launch_inst(const KArgs& a, hipStream_t stream) {
   if (nw == 3) nw = 4;
   long long nwg = (n_wt + nw - 1) / nw;
   const int grid = (int)(nwg < ncu ? nwg : ncu);
-  const size_t lds = sizeof(float) * ((size_t)a.T * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.T * COEF_STRIDE);
-  if (lds > 160 * 1024) { set_error("sampler: steps=%d needs %zu B of LDS (> 160 KiB)", a.T, lds); return FRL_EUNSUPPORTED; }
+  const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE);
+  if (lds > 160 * 1024) { set_error("sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
   static thread_local size_t configured[16] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -9,11 +9,11 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FRL_ABI_VERSION = 1
+FRL_ABI_VERSION = 2
 FRL_MAX_HIDDEN = 8
 
 FRL_KIND_DDPM, FRL_KIND_CDDPM, FRL_KIND_CNF = 0, 1, 2
-FRL_SOLVER_DDPM, FRL_SOLVER_DDIM, FRL_SOLVER_EULER = 0, 1, 2
+FRL_SOLVER_DDPM, FRL_SOLVER_DDIM, FRL_SOLVER_EULER, FRL_SOLVER_DPM2, FRL_SOLVER_DPMPP2M = 0, 1, 2, 3, 4
 FRL_TEMB_NONE, FRL_TEMB_POSITIONAL, FRL_TEMB_FOURIER = 0, 1, 2
 FRL_ACT = {"mish": 0, "silu": 1, "relu": 2, "gelu_tanh": 3, "gelu": 3, "tanh": 4, "elu": 5}
 FRL_DTYPE_F32, FRL_DTYPE_BF16 = 0, 1
@@ -43,7 +43,8 @@ class FrlParams(C.Structure):
 
 
 class FrlSchedule(C.Structure):
-    _fields_ = [("betas", _fp), ("alphas", _fp), ("alpha_hats", _fp), ("postvars", _fp), ("ts", _fp)]
+    _fields_ = [("betas", _fp), ("alphas", _fp), ("alpha_hats", _fp), ("postvars", _fp), ("ts", _fp),
+                ("mid_ts", _fp), ("mid_alphas", _fp), ("mid_sigmas", _fp)]
 
 
 class FrlFwdBufs(C.Structure):

@@ -178,12 +178,13 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
                       compute_dtype=compute_dtype)
     fparams = build_params(network, params, device, keep)
     fs = _lib.FrlSchedule()
-    for name in ("betas", "alphas", "alpha_hats", "postvars", "ts"):
+    for name in ("betas", "alphas", "alpha_hats", "postvars", "ts", "mid_ts", "mid_alphas", "mid_sigmas"):
         t = sched.get(name)
         if t is not None:
             t = _f32c(t, device, f"sched.{name}")
-            if t.numel() != steps + 1:
-                raise ValueError(f"sched.{name} has {t.numel()} entries, expected steps+1 = {steps + 1}")
+            want = steps if name.startswith("mid_") else steps + 1
+            if t.numel() != want:
+                raise ValueError(f"sched.{name} has {t.numel()} entries, expected {want}")
             keep.append(t)
             setattr(fs, name, t.data_ptr())
     if cond2d is not None:

@@ -1,5 +1,5 @@
 """Continuous-time VP diffusion sampler — host mirror of flowrl/flow/continuous_ddpm.py
-(class ContinuousDDPM, :47-222; solvers ddpm and ddim run fused, dpm2 / dpm++2m are not built)."""
+(class ContinuousDDPM, :47-222; all four solvers — ddpm, ddim, dpm2, dpm++2m — run in the fused f32 kernel)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, replace
@@ -61,21 +61,23 @@ class ContinuousDDPM:
         steps = steps or self.steps
         t_schedule_n = t_schedule_n or self.t_schedule_n
         solver = solver or self.solver
-        if solver not in ("ddpm", "ddim"):
-            if solver in ("dpm2", "dpm++2m"):
-                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, f"solver {solver} has no fused kernel yet")
-            raise NotImplementedError(f"Unsupported solver: {solver}")
+        solver_ids = {"ddpm": _lib.FRL_SOLVER_DDPM, "ddim": _lib.FRL_SOLVER_DDIM, "dpm2": _lib.FRL_SOLVER_DPM2,
+                      "dpm++2m": _lib.FRL_SOLVER_DPMPP2M}
+        if solver not in solver_ids:
+            raise NotImplementedError(f"Unsupported solver: {solver}")       # continuous_ddpm.py:215
         ts, ah, al, be = schedules.continuous_tables(steps, self.noise_schedule_func, self.t_diffusion, t_schedule_n)
         dev = xT.device
         to = lambda v: torch.from_numpy(v).to(dev)
         p = params if (training and params is not None) else self.params
         if solver == "ddpm" and noise is None:
             noise = draw_noise(rng, (steps, *xT.shape), xT.device)
+        sched = {"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)}
+        if solver == "dpm2":
+            mid, mal, msg = schedules.continuous_midpoints(ts, self.noise_schedule_func)
+            sched.update(mid_ts=to(mid), mid_alphas=to(mal), mid_sigmas=to(msg))
         x0, hist = run_sampler(
-            self.network, p, kind=_lib.FRL_KIND_CDDPM,
-            solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
-            steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
-            sched={"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)},
+            self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
+            steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
             particles=particles, compute_dtype=compute_dtype)
         return rng, x0, hist

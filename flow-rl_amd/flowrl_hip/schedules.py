@@ -81,3 +81,10 @@ def continuous_tables(steps: int, noise_schedule_func: Callable, t_diffusion, t_
     alphas = np.concatenate([np.ones((1,), F32), alpha_hats[1:] / alpha_hats[:-1]]).astype(F32)
     betas = (1 - alphas).astype(F32)
     return ts, alpha_hats, alphas, betas
+
+
+def continuous_midpoints(ts: np.ndarray, noise_schedule_func: Callable):
+    """(midpoints, mid_alphas, mid_sigmas), each (steps,) — the dpm2 tables of continuous_ddpm.py:145-147."""
+    mid = ((ts[:-1] + ts[1:]) / F32(2)).astype(F32)
+    al, sg = noise_schedule_func(mid)
+    return mid, np.asarray(al, F32), np.asarray(sg, F32)

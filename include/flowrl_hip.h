@@ -7,7 +7,7 @@
  * replaces (paths relative to the reference checkout):
  *
  *   DDPM.sample                        flowrl/flow/ddpm.py:173-221
- *   ContinuousDDPM.sample              flowrl/flow/continuous_ddpm.py:117-222   (solvers ddpm, ddim)
+ *   ContinuousDDPM.sample              flowrl/flow/continuous_ddpm.py:117-222   (solvers ddpm, ddim, dpm2, dpm++2m)
  *   ContinuousNormalizingFlow.sample   flowrl/flow/cnf.py:113-141
  *   DDPMBackbone / FlowBackbone        flowrl/flow/ddpm.py:70-95, flowrl/flow/cnf.py:17-42
  *   MLP (Dense -> act)*L -> Dense      flowrl/module/mlp.py:10-34, flowrl/agent/offline/fql/network.py:10-35
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FRL_ABI_VERSION 1
+#define FRL_ABI_VERSION 2
 #define FRL_MAX_HIDDEN 8 /* hidden Dense layers of the predictor MLP (mlp.py:25) */
 
 /* error codes */
@@ -49,6 +49,8 @@ extern "C" {
 #define FRL_SOLVER_DDPM 0  /* ddpm.py:198-206 / continuous_ddpm.py:170-174 */
 #define FRL_SOLVER_DDIM 1  /* ddpm.py:207-213 / continuous_ddpm.py:176-177 */
 #define FRL_SOLVER_EULER 2 /* cnf.py:92-111 */
+#define FRL_SOLVER_DPM2 3    /* continuous_ddpm.py:179-196  DPM-Solver-2: midpoint, TWO network evaluations per step */
+#define FRL_SOLVER_DPMPP2M 4 /* continuous_ddpm.py:198-212  DPM-Solver++(2M): multistep, carries the previous x0_hat  */
 
 #define FRL_TEMB_NONE 0       /* raw scalar t concatenated (FQL: cnf.py:30-41 with time_embedding=None) */
 #define FRL_TEMB_POSITIONAL 1 /* time_embedding.py:6-16  */
@@ -106,7 +108,8 @@ typedef struct FrlParams {
 
 /* Noise-schedule tables, each (T+1,) float32 on the device.
  * DDPM:  the model's own pytree leaves betas/alphas/alpha_hats/postvars (ddpm.py:108-111), verbatim.
- * CDDPM: the per-call tables of continuous_ddpm.py:134-138 (postvars unused, ts required).
+ * CDDPM: the per-call tables of continuous_ddpm.py:134-138 (postvars unused, ts required); the log-SNR table of
+ *        dpm++2m (continuous_ddpm.py:141-142) is derived from alpha_hats by frl_sampler_prepare.
  * CNF:   all NULL. */
 typedef struct FrlSchedule {
   const float* betas;
@@ -114,6 +117,11 @@ typedef struct FrlSchedule {
   const float* alpha_hats;
   const float* postvars;
   const float* ts;
+  /* FRL_SOLVER_DPM2 only, each (T,) with entry i-1 belonging to loop index i (continuous_ddpm.py:145-147):
+   * the interval midpoints (ts[:-1] + ts[1:]) / 2 and noise_schedule_func evaluated there */
+  const float* mid_ts;
+  const float* mid_alphas;
+  const float* mid_sigmas;
 } FrlSchedule;
 
 typedef struct FrlFwdBufs {

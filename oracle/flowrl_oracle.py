@@ -334,20 +334,34 @@ def ddpm_sample(spec: BackboneSpec, params: Dict, tables, xT, condition, noise, 
 
 
 def continuous_ddpm_sample(spec: BackboneSpec, params: Dict, tables, xT, condition, noise, *, steps: int,
-                           solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None):
-    """ContinuousDDPM.sample — continuous_ddpm.py:117-222 (solvers ddpm / ddim).
-    ``tables`` = (ts, alpha_hats, alphas, betas) from :func:`continuous_tables`."""
+                           solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None,
+                           noise_schedule: str = "cosine", noise_schedule_params: Optional[dict] = None):
+    """ContinuousDDPM.sample — continuous_ddpm.py:117-222 (solvers ddpm / ddim / dpm2 / dpm++2m).
+    ``tables`` = (ts, alpha_hats, alphas, betas) from :func:`continuous_tables`; ``noise_schedule`` names the
+    (alpha, sigma)(t) function dpm2 evaluates at the interval midpoints (continuous_ddpm.py:145-147)."""
     dt = xT.dtype
     ts, alpha_hats, alphas, betas = [np.asarray(a, dtype=dt) for a in tables]
     xt = xT
     xt_hist, eps_hist = [], []
     one = np.ones((), dtype=dt)
+    if solver == "dpm++2m":      # continuous_ddpm.py:141-142
+        lambdas = np.log(np.sqrt(alpha_hats) / np.sqrt(np.maximum(one - alpha_hats, np.asarray(1e-12, dtype=dt))))
+    if solver == "dpm2":         # continuous_ddpm.py:145-147
+        fn = {"cosine": cosine_noise_schedule, "linear": linear_noise_schedule}[noise_schedule]
+        midpoints = ((ts[:-1] + ts[1:]) / np.asarray(2, dtype=dt)).astype(dt)
+        mid_alphas, mid_sigmas = [np.asarray(v, dtype=dt) for v in fn(midpoints, **dict(noise_schedule_params or {}))]
+    prev_x0_hat = np.zeros_like(xT)          # scan carry, continuous_ddpm.py:219
+    prev_h = np.zeros((), dtype=dt)
+
+    def net(x, tval):
+        return backbone_apply(spec, params, x, np.ones((*xT.shape[:-1], 1), dtype=dt) * tval, condition)
+
     for j, i in enumerate(range(steps, 0, -1)):
-        input_t = np.ones((*xT.shape[:-1], 1), dtype=dt) * ts[i]
-        eps = backbone_apply(spec, params, xt, input_t, condition)
+        eps = net(xt, ts[i])
         x0_hat = (xt - np.sqrt(one - alpha_hats[i]) * eps) / np.sqrt(alpha_hats[i])
         if clip_sampler:
             x0_hat = _clip(x0_hat, x_min, x_max)
+        h = np.zeros((), dtype=dt)
         if solver == "ddpm":
             c1 = np.sqrt(alpha_hats[i - 1]) * betas[i] / (one - alpha_hats[i])
             c2 = np.sqrt(alphas[i]) * (one - alpha_hats[i - 1]) / (one - alpha_hats[i])
@@ -355,10 +369,29 @@ def continuous_ddpm_sample(spec: BackboneSpec, params: Dict, tables, xT, conditi
             xt_1 = xt_1 + np.asarray(float(i > 1), dtype=dt) * np.sqrt(betas[i]) * noise[j]
         elif solver == "ddim":
             xt_1 = np.sqrt(alpha_hats[i - 1]) * x0_hat + np.sqrt(one - alpha_hats[i - 1]) * eps
+        elif solver == "dpm2":               # continuous_ddpm.py:179-196: midpoint method, 2 network evaluations
+            x_s = mid_alphas[i - 1] * x0_hat + mid_sigmas[i - 1] * eps
+            eps_s = net(x_s.astype(dt), midpoints[i - 1])
+            x0c = (xt - np.sqrt(one - alpha_hats[i]) * eps_s) / np.sqrt(alpha_hats[i])
+            if clip_sampler:
+                x0c = _clip(x0c, x_min, x_max)
+            xt_1 = np.sqrt(alpha_hats[i - 1]) * x0c + np.sqrt(one - alpha_hats[i - 1]) * eps_s
+        elif solver == "dpm++2m":            # continuous_ddpm.py:198-212: multistep, carries (x0_hat, h)
+            h = (lambdas[i - 1] - lambdas[i]).astype(dt)
+            sigma_curr, sigma_next = np.sqrt(one - alpha_hats[i]), np.sqrt(one - alpha_hats[i - 1])
+            alpha_next = np.sqrt(alpha_hats[i - 1])
+            r = prev_h / np.maximum(h, np.asarray(1e-8, dtype=dt))
+            if prev_h > 1e-8:
+                half_over_r = np.asarray(0.5, dtype=dt) / r
+                d = (one + half_over_r) * x0_hat - half_over_r * prev_x0_hat
+            else:
+                d = x0_hat
+            xt_1 = (sigma_next / sigma_curr) * xt - alpha_next * np.expm1(-h) * d
         else:
             raise NotImplementedError(f"Unsupported solver: {solver}")
         xt_hist.append(xt)
         eps_hist.append(eps)
+        prev_x0_hat, prev_h = x0_hat, h
         xt = xt_1.astype(dt)
     return xt, (np.stack(xt_hist), np.stack(eps_hist))
 

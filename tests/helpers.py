@@ -64,7 +64,8 @@ def oracle_run(c: Case, params, xT, cond, noise, dtype=np.float64):
         x0, (xh, eh) = orc.ddpm_sample(c.spec, p, [t.astype(dtype) for t in tables], x, cd, nz, solver=c.solver, **kw)
     elif c.kind == "cddpm":
         tables = orc.continuous_tables(c.T, c.schedule, dtype=np.float32)
-        x0, (xh, eh) = orc.continuous_ddpm_sample(c.spec, p, [t.astype(dtype) for t in tables], x, cd, nz, solver=c.solver, **kw)
+        x0, (xh, eh) = orc.continuous_ddpm_sample(c.spec, p, [t.astype(dtype) for t in tables], x, cd, nz, solver=c.solver,
+                                                  noise_schedule=c.schedule, **kw)
     else:
         x0, (xh, eh) = orc.cnf_sample(c.spec, p, x, cd, **kw)
     return x0, xh, eh

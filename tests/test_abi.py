@@ -60,6 +60,10 @@ def test_algorithmic_flops_match_survey(lib):
     assert 0.9 * alg < ex.value < 1.0 * alg      # time slice hoisted (-64 rows), edge layers padded
     d = _desc(x_dim=2, cond_dim=1, steps=20, n_states=4096)   # cfg1: 148,736 MACs
     assert lib.frl_algorithmic_flops(C.byref(d), None) == 2.0 * 4096 * 20 * 148736
+    # dpm2 evaluates the network twice per step (continuous_ddpm.py:163,191)
+    d = _desc(kind=_lib.FRL_KIND_CDDPM, time_embed=_lib.FRL_TEMB_FOURIER, solver=_lib.FRL_SOLVER_DPM2)
+    assert lib.frl_validate(C.byref(d)) == _lib.FRL_OK
+    assert lib.frl_algorithmic_flops(C.byref(d), None) == 2.0 * 262144 * 10 * 151808
 
 
 @pytest.mark.parametrize("kw,code", [
@@ -73,7 +77,11 @@ def test_algorithmic_flops_match_survey(lib):
     (dict(time_dim=7), _lib.FRL_EINVAL),
     (dict(x_min=2.0, x_max=1.0), _lib.FRL_EINVAL),
     (dict(kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_DDPM), _lib.FRL_EINVAL),
-    (dict(solver=5), _lib.FRL_EUNSUPPORTED),
+    (dict(solver=5), _lib.FRL_EINVAL),
+    (dict(solver=_lib.FRL_SOLVER_DPM2), _lib.FRL_EINVAL),            # the discrete DDPM knows ddpm / ddim only (ddpm.py:16-18)
+    (dict(kind=_lib.FRL_KIND_CDDPM, time_embed=_lib.FRL_TEMB_FOURIER, solver=_lib.FRL_SOLVER_DPMPP2M, dtype=_lib.FRL_DTYPE_BF16),
+     _lib.FRL_EUNSUPPORTED),
+    (dict(kind=_lib.FRL_KIND_CDDPM, time_embed=_lib.FRL_TEMB_FOURIER, solver=_lib.FRL_SOLVER_DPM2, steps=200), _lib.FRL_EUNSUPPORTED),
     (dict(dtype=_lib.FRL_DTYPE_BF16, x_dim=33), _lib.FRL_EUNSUPPORTED),
     (dict(dtype=_lib.FRL_DTYPE_BF16, act=_lib.FRL_ACT["tanh"]), _lib.FRL_EUNSUPPORTED),
     (dict(dtype=7), _lib.FRL_EINVAL),

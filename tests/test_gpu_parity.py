@@ -110,6 +110,22 @@ def test_cddpm_linear_ddim():
                   solver="ddim", seed=10))
 
 
+@pytest.mark.parametrize("solver", ["dpm2", "dpm++2m"])
+def test_cddpm_dpm_solvers(solver):
+    # continuous_ddpm.py:179-212: midpoint DPM-Solver-2 (two network evaluations per step) and multistep DPM-Solver++(2M)
+    tag = solver.replace("+", "p")
+    _check(H.Case(f"cddpm-cosine-{tag}", "cddpm", A=6, S=17, T=20, B=200, temb="learnable_fourier", schedule="cosine",
+                  solver=solver, seed=30))
+    _check(H.Case(f"cddpm-linear-noclip-{tag}", "cddpm", A=3, S=11, T=10, B=70, temb="learnable_fourier", schedule="linear",
+                  solver=solver, clip=False, seed=31))
+    _check(H.Case(f"cddpm-wide-particles-{tag}", "cddpm", A=17, S=128, T=8, B=12 * 8, particles=8, temb="learnable_fourier",
+                  schedule="cosine", solver=solver, seed=32))
+    _check(H.Case(f"cddpm-512-{tag}", "cddpm", A=3, S=11, T=6, B=40, hidden=(512, 512), temb="positional", schedule="cosine",
+                  solver=solver, seed=33))
+    _check(H.Case(f"cddpm-T1-{tag}", "cddpm", A=3, S=11, T=1, B=33, temb="learnable_fourier", schedule="cosine", solver=solver,
+                  seed=34), history=False)
+
+
 def test_cnf_euler_raw_time():
     # FQL-style FlowBackbone without time embedding (raw t concatenated), 256-wide
     _check(H.Case("cnf-raw-t", "cnf", A=8, S=20, T=10, B=300, temb=None, clip=False, seed=11))
