@@ -206,7 +206,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
-  a.NE = pl.NE;
+  a.NE = pl.NE; a.AO = pl.AO;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
@@ -316,7 +316,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
-  a.NE = pl.NE;
+  a.NE = pl.NE; a.AO = pl.AO;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
@@ -334,6 +334,97 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   b.Dp = Dp;
   b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
   return bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stream);
+}
+
+// ---- critic scoring + best-of-N selection ------------------------------------------------------
+static int critic_plan(const FrlCriticDesc* c, FrlDesc& d, Plan& pl) {
+  if (c == nullptr) { set_error("critic desc is NULL"); return FRL_EINVAL; }
+  if (c->abi_version != FRL_ABI_VERSION) { set_error("critic desc.abi_version %d != library %d", c->abi_version, FRL_ABI_VERSION); return FRL_EINVAL; }
+  if (c->ensemble < 1 || c->ensemble > 16) { set_error("ensemble %d outside [1, 16]", c->ensemble); return FRL_EINVAL; }
+  if (c->act_dim < 1 || c->obs_dim < 0) { set_error("act_dim %d / obs_dim %d invalid", c->act_dim, c->obs_dim); return FRL_EINVAL; }
+  memset(&d, 0, sizeof(d));
+  d.abi_version = FRL_ABI_VERSION;
+  d.kind = FRL_KIND_CNF; d.solver = FRL_SOLVER_EULER; d.steps = 1;      // carrier only: the mode is overridden below
+  d.n_states = c->n_states; d.particles = c->particles;
+  d.x_dim = c->act_dim; d.cond_dim = c->obs_dim;
+  d.time_embed = FRL_TEMB_NONE; d.time_dim = 0;
+  d.n_hidden = c->n_hidden;
+  for (int l = 0; l < FRL_MAX_HIDDEN; ++l) d.hidden[l] = (l < c->n_hidden) ? c->hidden[l] : 0;
+  d.act = c->act; d.dtype = FRL_DTYPE_F32;
+  int rc = validate_desc(&d);
+  if (rc != FRL_OK) return rc;
+  // ScalarCritic: x = concat([obs, action]) (critic.py:185-188) -> backbone MLP -> Dense(1): no time rows, the action
+  // rows FOLLOW the observation rows, one output
+  pl.A = d.x_dim; pl.C = d.cond_dim; pl.T = 1; pl.L = d.n_hidden; pl.D = 0; pl.Dp = 0;
+  pl.AO = 1; pl.x_row0 = pl.C; pl.c_row0 = 0;
+  pl.H = d.hidden[0];
+  plan_layout(d, pl);
+  pl.mode = MODE_EVAL;
+  return FRL_OK;
+}
+
+size_t frl_critic_workspace_bytes(const FrlCriticDesc* desc) {
+  FrlDesc d; Plan pl;
+  if (critic_plan(desc, d, pl) != FRL_OK) return 0;
+  const size_t B = (size_t)pl.B;
+  return ((size_t)desc->ensemble * pl.total_floats + (((size_t)desc->ensemble * B + 63) & ~(size_t)63)) * sizeof(float);
+}
+
+int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, const FrlSelectBufs* bufs,
+                      void* workspace, size_t workspace_bytes, void* hip_stream) {
+  FrlDesc d; Plan pl;
+  int rc = critic_plan(desc, d, pl);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
+  const size_t need = frl_critic_workspace_bytes(desc);
+  if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (workspace_bytes < need) { set_error("workspace %zu B < required %zu B", workspace_bytes, need); return FRL_EWORKSPACE; }
+  if (pl.B == 0) return FRL_OK;
+  if (bufs->actions == nullptr) { set_error("bufs.actions is NULL"); return FRL_EINVAL; }
+  if ((desc->obs_dim > 0) != (bufs->obs != nullptr)) { set_error("bufs.obs must be non-NULL exactly when obs_dim > 0"); return FRL_EINVAL; }
+  if (bufs->q == nullptr && bufs->best_idx == nullptr && bufs->best_action == nullptr) { set_error("no output requested (q / best_idx / best_action all NULL)"); return FRL_EINVAL; }
+  for (int l = 0; l <= desc->n_hidden; ++l)
+    if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const int E = desc->ensemble, L = pl.L, H = pl.H, K0 = pl.C + pl.A;
+  float* ws = (float*)workspace;
+  float* qm = ws + (size_t)E * pl.total_floats;                      // (E, B) member scores
+  for (int e = 0; e < E; ++e) {
+    // member e of every stacked leaf (Ensemblize: nn.vmap with variable_axes params = 0, critic.py:154-172)
+    PArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    for (int l = 0; l <= L; ++l) {
+      const size_t rows = (l == 0) ? (size_t)K0 : (size_t)H, cols = (l == L) ? 1 : (size_t)H;
+      pa.p.kernel[l] = params->kernel[l] + (size_t)e * rows * cols;
+      pa.p.bias[l] = params->bias[l] + (size_t)e * cols;
+    }
+    float* wse = ws + (size_t)e * pl.total_floats;
+    pa.ws = wse; pa.plan = pl; pa.kind = FRL_KIND_CNF; pa.time_embed = FRL_TEMB_NONE;
+    rc = launch_prepare(pa, stream);
+    if (rc != FRL_OK) return rc;
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xT = bufs->actions; a.cond = bufs->obs; a.x0 = qm + (size_t)e * pl.B;
+    for (int l = 1; l < L; ++l) { a.wh[l - 1] = pa.p.kernel[l]; a.bh[l - 1] = pa.p.bias[l]; }
+    a.ws_coef = wse + pl.off_coef; a.ws_tb = wse + pl.off_tb; a.ws_w0p = wse + pl.off_w0p;
+    a.ws_wlp = wse + pl.off_wlp; a.ws_wlq = wse + pl.off_wlq; a.ws_blp = wse + pl.off_blp;
+    a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = 1; a.L = L; a.H = H; a.TR = pl.TR;
+    a.NE = 1; a.AO = 1;
+    a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
+    a.mode = MODE_EVAL;
+    a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
+    switch (desc->act) {
+      case FRL_ACT_MISH: rc = launch_sampler_rs_act<FRL_ACT_MISH>(a, stream); break;
+      case FRL_ACT_SILU: rc = launch_sampler_rs_act<FRL_ACT_SILU>(a, stream); break;
+      case FRL_ACT_RELU: rc = launch_sampler_rs_act<FRL_ACT_RELU>(a, stream); break;
+      case FRL_ACT_GELU_TANH: rc = launch_sampler_rs_act<FRL_ACT_GELU_TANH>(a, stream); break;
+      case FRL_ACT_TANH: rc = launch_sampler_rs_act<FRL_ACT_TANH>(a, stream); break;
+      default: rc = launch_sampler_rs_act<FRL_ACT_ELU>(a, stream); break;
+    }
+    if (rc != FRL_OK) return rc;
+  }
+  return launch_critic_select(qm, E, desc->n_states, desc->particles, pl.A, bufs->actions, bufs->gumbel, bufs->inv_temperature,
+                              bufs->q, bufs->best_idx, bufs->best_action, stream);
 }
 
 int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream) {

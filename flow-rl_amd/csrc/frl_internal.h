@@ -33,6 +33,7 @@ enum Mode : int {
   MODE_CNF_EULER = 4,   // cnf.py:108-110
   MODE_CDDPM_DPMPP2M = 5,  // continuous_ddpm.py:198-212 (carries the previous x0_hat in registers)
   MODE_CDDPM_DPM2 = 6,     // continuous_ddpm.py:179-196 (two network evaluations per step: NE = 2 T)
+  MODE_EVAL = 7,           // one plain network evaluation, output = the net's AO outputs (critic scoring, critic.py:178-194)
 };
 
 // FRL_GEO=16 selects the 16x16x4 geometry for 256-wide nets too (A/B measurements)
@@ -44,6 +45,8 @@ inline bool prefer_tr16() {
 // Derived sizes of one call (host + device agree through this one function).
 struct Plan {
   int A, C, D, Dp;      // action dim, cond dim, time_dim, D' (= D or 1) rows of Dense_0 taken by time
+  int AO;               // network outputs (= A for the samplers; 1 for a critic)
+  int x_row0, c_row0;   // first Dense_0 kernel row of the x / cond inputs (samplers: x | time | cond; critic: obs | action)
   int H, L, T;
   int NE;               // network evaluations per chain = rows of the coefficient / bias tables (T; 2 T for dpm2)
   int TR, KS, NR;       // geometry: MFMA tile rows (32: 32x32x2, 16: 16x16x4), k per MFMA, accumulators per block
@@ -68,11 +71,19 @@ struct Plan {
   size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
 };
 
+inline int plan_layout(const FrlDesc& d, Plan& p);
+
 inline int plan_from_desc(const FrlDesc& d, Plan& p) {
   p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps; p.L = d.n_hidden;
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
+  p.AO = p.A; p.x_row0 = 0; p.c_row0 = p.A + p.Dp;
   p.H = d.hidden[0];
+  return plan_layout(d, p);
+}
+
+// Second half of the plan: geometry and workspace layout from the (possibly overridden) dims above.
+inline int plan_layout(const FrlDesc& d, Plan& p) {
   p.TR = (p.H <= 256 && !prefer_tr16()) ? 32 : 16;
   p.KS = (p.TR == 32) ? 2 : 4;
   p.NR = (p.TR == 32) ? 16 : 4;
@@ -121,6 +132,7 @@ struct KArgs {
   long long B;
   int particles, A, C, T, L, H, TR, mode, clip;
   int NE;                                 // network evaluations per chain (table rows); = T except dpm2
+  int AO;                                 // network outputs per chain (= A except MODE_EVAL)
   int w0p_bytes;
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;
@@ -229,6 +241,9 @@ int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);  
 size_t bf16_lds_bytes(int T, int L);
 int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim, const float* w0, const float* b0,
                        const float* w1, const float* b1, float* cfeat, hipStream_t stream);
+int launch_critic_select(const float* q_members, int E, long long n_states, int particles, int A, const float* actions,
+                         const float* gumbel, float inv_temperature, float* q, int32_t* best_idx, float* best_action,
+                         hipStream_t stream);
 int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);
 
 }  // namespace frl

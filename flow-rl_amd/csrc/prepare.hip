@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   extern __shared__ float sh[];  // 3 * NE * Dmax floats
   const Plan& pl = a.plan;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int T = pl.T, H = pl.H, A = pl.A, C = pl.C, D = pl.D, Dp = pl.Dp;
+  const int T = pl.T, H = pl.H, A = pl.A, C = pl.C, D = pl.D, Dp = pl.Dp, AO = pl.AO;
   float* ws = a.ws;
   float* coef = ws + pl.off_coef;
   float* tb = ws + pl.off_tb;
@@ -47,7 +47,9 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     float c[COEF_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
     float tv;
     const int j = (pl.mode == MODE_CDDPM_DPM2) ? e >> 1 : e;     // loop iteration of the reference's scan
-    if (pl.mode == MODE_CNF_EULER) {
+    if (pl.mode == MODE_EVAL) {
+      tv = 0.0f;                             // plain evaluation: no time input, no update rule
+    } else if (pl.mode == MODE_CNF_EULER) {
       tv = (float)j / (float)T;              // step2t(arange(steps)), cnf.py:80-83,139
       c[0] = (float)T;                       // x_next = xt + vel / steps, cnf.py:108
     } else {
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     // raw scalar time is input column A of Dense_0 (cnf.py:38-41)
     for (int idx = tid; idx < NE * H; idx += nt) {
       const int j = idx / H, f = idx - j * H;
-      tb[idx] = fmaf(tvals[j], W0[(size_t)A * H + f], b0[f]);
+      tb[idx] = (Dp == 0) ? b0[f] : fmaf(tvals[j], W0[(size_t)A * H + f], b0[f]);
     }
   } else {
     const int half = D / 2;
@@ -174,10 +176,10 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     const int r = idx / H, f = idx - r * H;
     float v = 0.0f;
     if (r < pl.XR) {
-      if (r < A) v = W0[(size_t)r * H + f];
+      if (r < A) v = W0[(size_t)(pl.x_row0 + r) * H + f];
     } else {
       const int k = r - pl.XR;
-      if (k < C) v = W0[(size_t)(A + Dp + k) * H + f];
+      if (k < C) v = W0[(size_t)(pl.c_row0 + k) * H + f];
     }
     w0p[idx] = v;
   }
@@ -186,9 +188,9 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   const float* WL = a.p.kernel[pl.L];
   for (int idx = tid; idx < HL * LAST_PAD; idx += nt) {
     const int k = idx / LAST_PAD, i = idx - k * LAST_PAD;
-    wlp[idx] = (i < A) ? WL[(size_t)k * A + i] : 0.0f;
+    wlp[idx] = (i < AO) ? WL[(size_t)k * AO + i] : 0.0f;
   }
-  for (int i = tid; i < LAST_PAD; i += nt) blp[i] = (i < A) ? a.p.bias[pl.L][i] : 0.0f;
+  for (int i = tid; i < LAST_PAD; i += nt) blp[i] = (i < AO) ? a.p.bias[pl.L][i] : 0.0f;
   // ---- last layer, per-lane packed: load q (16 B per lane) = A operands of k-steps 4q..4q+3, k = block*NR + r,
   //      lane (i = lane % TR, s = lane / TR) contracts feature GW*g + j + 4*(ROWR(r) + 4 s), block = 4 g + j ----
   {
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
       const int rowr = (TR == 32) ? ((r & 3) + 8 * (r >> 2)) : ((r & 3) + 16 * (r >> 2));
       const int i = lane % TR, sl = lane / TR;
       const int kf = GW * (blk >> 2) + (blk & 3) + 4 * (rowr + 4 * sl);
-      wlq[idx] = (i < A && kf < HL) ? WL[(size_t)kf * A + i] : 0.0f;
+      wlq[idx] = (i < AO && kf < HL) ? WL[(size_t)kf * AO + i] : 0.0f;
     }
   }
 }

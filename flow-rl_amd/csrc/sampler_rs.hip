@@ -269,6 +269,8 @@ frl_sampler_rs_kernel(const KArgs a) {
           const float d = c4 * x0h - c5 * aux[r];                   // :207-211 (c4 = 1, c5 = 0 on the first-order step)
           xn = c2 * xt - c3 * d;                                    // :212
           aux[r] = x0h;                                             // carry, :217
+        } else if (a.mode == MODE_EVAL) {
+          xn = eps;                                                 // plain evaluation: the outputs themselves
         } else if (a.mode == MODE_CDDPM_DPM2) {
           const float xo = (c6 == 0.0f) ? xt : aux[r];              // both x0_hats come from the ORIGINAL xt, :165,:194
           float x0h = (xo - c1 * eps) / c0;
@@ -279,14 +281,14 @@ frl_sampler_rs_kernel(const KArgs a) {
           xn = xt + eps / c0;                                       // cnf.py:108
           if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
         }
-        xs[r] = in ? xn : 0.0f;
+        xs[r] = (a.mode == MODE_EVAL) ? ((valid && ai < a.AO) ? xn : 0.0f) : (in ? xn : 0.0f);
       });
     }
 
     sfor<NRX>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
       const int ai = G::rowr(r) + 4 * ls;
-      if (valid && ai < a.A) a.x0[chain * a.A + ai] = xs[r];
+      if (valid && ai < a.AO) a.x0[chain * a.AO + ai] = xs[r];
     });
   }
 }

@@ -4,6 +4,7 @@ Drop-in surface (same names, argument order and return structure as the referenc
   flowrl_hip.flow.ddpm.DDPM.sample                        <- flowrl/flow/ddpm.py:173-221
   flowrl_hip.flow.continuous_ddpm.ContinuousDDPM.sample   <- flowrl/flow/continuous_ddpm.py:117-222
   flowrl_hip.flow.cnf.ContinuousNormalizingFlow.sample    <- flowrl/flow/cnf.py:113-141
+  flowrl_hip.critic.critic_select / sample_and_select     <- flowrl/agent/offline/dql.py:130-162 (critic best-of-N)
 All arithmetic runs in libflowrl_hip.so (hand-written HIP for gfx950) through the C ABI in
 include/flowrl_hip.h; there is no CPU / eager fallback.
 """
@@ -13,3 +14,4 @@ from . import _lib  # noqa: F401
 from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, PositionalEmbedding,  # noqa: F401
                      LearnableFourierEmbedding, init_params, tree_from_numpy, tree_to)
 from ._lib import FlowRLHipError, FlowRLHipUnsupported  # noqa: F401
+from .critic import Ensemblize, ScalarCritic, critic_select, init_critic_params, sample_and_select  # noqa: F401

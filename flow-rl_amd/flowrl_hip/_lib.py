@@ -56,6 +56,21 @@ class FrlBwdBufs(C.Structure):
                 ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_tb", _fp)]
 
 
+class FrlCriticDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("particles", C.c_int32), ("n_states", C.c_int64), ("obs_dim", C.c_int32),
+                ("act_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32 * FRL_MAX_HIDDEN), ("act", C.c_int32),
+                ("ensemble", C.c_int32)]
+
+
+class FrlCriticParams(C.Structure):
+    _fields_ = [("kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("bias", _fp * (FRL_MAX_HIDDEN + 1))]
+
+
+class FrlSelectBufs(C.Structure):
+    _fields_ = [("obs", _fp), ("actions", _fp), ("gumbel", _fp), ("inv_temperature", C.c_float), ("q", _fp),
+                ("best_idx", _fp), ("best_action", _fp)]
+
+
 class FlowRLHipError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libflowrl_hip error {code}: {msg}")
@@ -84,6 +99,9 @@ EXPORTS = {
     "frl_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
     "frl_sampler_bwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule), C.POINTER(FrlBwdBufs),
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_critic_workspace_bytes": (C.c_size_t, [C.POINTER(FrlCriticDesc)]),
+    "frl_critic_select": (C.c_int, [C.POINTER(FrlCriticDesc), C.POINTER(FrlCriticParams), C.POINTER(FrlSelectBufs),
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_selftest_mfma32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

@@ -181,6 +181,51 @@ size_t frl_bwd_workspace_bytes(const FrlDesc* desc);
 int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlBwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* ---- critic scoring + best-of-N selection: the step right after every multi-particle sample ----------------------
+ * Replaces, in jit_sample_and_select (flowrl/agent/offline/dql.py:151-161, dac.py:172-182) and jit_sample_actions
+ * (flowrl/agent/online/qvpo.py:39-43, sdac.py:41-45):
+ *     qs = critic(obs_repeat, actions)                    Ensemblize(ScalarCritic(MLP)), flowrl/module/critic.py:154-194
+ *     qs = qs.min(axis=0).reshape(B, num_samples)
+ *     idx = qs.argmax(-1)   |   jax.random.categorical(key, logits = qs / (1e-6 + temperature))
+ *     actions = actions.reshape(B, num_samples, -1)[arange(B), idx]
+ * obs is passed UN-repeated (n_states, obs_dim); the kernel broadcasts each row over its particles.  The categorical
+ * draw is argmax(logits + Gumbel noise): the caller supplies the noise (drawn with the reference's key), like the
+ * sampler's N(0, I) noise; gumbel = NULL selects the plain argmax (first maximum, as jnp.argmax). */
+typedef struct FrlCriticDesc {
+  int32_t abi_version; /* FRL_ABI_VERSION */
+  int32_t particles;   /* num_samples: candidate actions per state */
+  int64_t n_states;
+  int32_t obs_dim;     /* S: rows [0, S) of the backbone's Dense_0 kernel (critic.py:187: concat([obs, action])) */
+  int32_t act_dim;     /* A: rows [S, S + A) */
+  int32_t n_hidden;    /* hidden Dense layers of the backbone MLP */
+  int32_t hidden[FRL_MAX_HIDDEN];
+  int32_t act;         /* FRL_ACT_* (mish in DQL / DAC, relu in QVPO: dql.py:227, qvpo.yaml:7) */
+  int32_t ensemble;    /* E: ensemble_size */
+} FrlCriticDesc;
+
+/* Leaves of Model.create(Ensemblize(ScalarCritic(MLP))): every leaf carries the ensemble axis first (nn.vmap,
+ * variable_axes = {"params": 0}). */
+typedef struct FrlCriticParams {
+  const float* kernel[FRL_MAX_HIDDEN + 1]; /* backbone/Dense_i/kernel (E, in, H), i < L; [L] = the head Dense_0/kernel (E, H, 1) */
+  const float* bias[FRL_MAX_HIDDEN + 1];   /* backbone/Dense_i/bias (E, H); [L] = the head bias (E, 1) */
+} FrlCriticParams;
+
+typedef struct FrlSelectBufs {
+  const float* obs;      /* (n_states, S), NULL iff obs_dim == 0 */
+  const float* actions;  /* (n_states * particles, A): the sampler's x0 */
+  const float* gumbel;   /* (n_states, particles) Gumbel(0, 1) noise or NULL */
+  float inv_temperature; /* 1 / (1e-6 + temperature); used only with gumbel */
+  float* q;              /* (n_states, particles) min over the ensemble, or NULL */
+  int32_t* best_idx;     /* (n_states,) or NULL */
+  float* best_action;    /* (n_states, A) or NULL */
+} FrlSelectBufs;
+
+size_t frl_critic_workspace_bytes(const FrlCriticDesc* desc);
+
+/* E launches of the fused MFMA network kernel (one evaluation per chain, no update rule) + one selection kernel. */
+int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, const FrlSelectBufs* bufs,
+                      void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Algorithmic FLOPs of one call, SURVEY.md section 8(d): 2*B*T*(K0*H + sum H_l*H_{l+1} + H*A) with
  * the reference's full K0 = A + D' + C; `executed` (may be NULL) receives the MFMA FLOPs the kernel
  * really issues (time slice hoisted, edge layers zero-padded). */

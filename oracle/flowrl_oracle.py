@@ -416,6 +416,54 @@ def cnf_sample(spec: BackboneSpec, params: Dict, x0, condition, *, steps: int,
 
 
 # --------------------------------------------------------------------------- #
+# critic scoring + best-of-N selection — flowrl/module/critic.py:154-194, flowrl/agent/offline/dql.py:151-161
+# --------------------------------------------------------------------------- #
+
+
+def critic_apply(params: Dict, obs, action, n_hidden: int, activation: str):
+    """Ensemblize(ScalarCritic(MLP)): every leaf carries the ensemble axis first (nn.vmap, variable_axes params = 0,
+    in_axes=None: all members see the same input).  Returns (E, ..., 1)."""
+    act = get_activation(activation)
+    x = action if obs is None else np.concatenate([obs, action], axis=-1)      # critic.py:185-188
+    out = []
+    E = params["base"]["Dense_0"]["kernel"].shape[0]
+    for e in range(E):
+        h = x
+        for i in range(n_hidden):
+            d = params["base"]["backbone"][f"Dense_{i}"]
+            h = act(h @ d["kernel"][e] + d["bias"][e])
+        d = params["base"]["Dense_0"]
+        out.append(h @ d["kernel"][e] + d["bias"][e])
+    return np.stack(out)
+
+
+def select_best(params: Dict, obs, actions, n_hidden: int, activation: str, temperature=0.0, gumbel=None):
+    """dql.py:145,151-161 after the sampler: obs (B, S), actions (B, N, A).  Returns (chosen (B, A), idx (B,), qs (B, N)).
+    temperature > 0: jax.random.categorical(key, logits) == argmax(logits + Gumbel(key)); the noise is an input."""
+    B, N = actions.shape[0], actions.shape[1]
+    obs_repeat = None if obs is None else np.repeat(obs[:, None, :], N, axis=1)
+    qs = critic_apply(params, obs_repeat, actions, n_hidden, activation)       # (E, B, N, 1)
+    qs = qs.min(axis=0).reshape(B, N)
+    if temperature is None or temperature <= 0.0:
+        idx = qs.argmax(axis=-1)
+    else:
+        idx = (qs / np.asarray(1e-6 + temperature, dtype=qs.dtype) + gumbel).argmax(axis=-1)
+    return actions[np.arange(B), idx], idx, qs
+
+
+def make_critic_params(obs_dim: int, act_dim: int, hidden_dims, ensemble: int, seed: int, dtype=np.float32, bias_std=0.1) -> Dict:
+    rng = np.random.default_rng(seed)
+    dims = [obs_dim + act_dim, *hidden_dims]
+
+    def stacked(n_in, n_out):
+        ms = [_dense_params(rng, n_in, n_out, dtype, bias_std) for _ in range(ensemble)]
+        return {"kernel": np.stack([m["kernel"] for m in ms]), "bias": np.stack([m["bias"] for m in ms])}
+
+    return {"base": {"backbone": {f"Dense_{i}": stacked(dims[i], dims[i + 1]) for i in range(len(hidden_dims))},
+                     "Dense_0": stacked(dims[-1], 1)}}
+
+
+# --------------------------------------------------------------------------- #
 # synthetic parameters (SURVEY.md section 8d "Synthetic values & seeds")
 # --------------------------------------------------------------------------- #
 

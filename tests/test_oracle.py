@@ -316,3 +316,31 @@ def test_bf16_round_matches_torch():
     want = torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
     assert np.array_equal(orc.bf16_round(a), want)
     assert orc.bf16_round(a.astype(np.float32)).dtype == np.float32
+
+
+def test_critic_select_known_answers():
+    """critic.py:154-194 + dql.py:151-161.  A critic whose members are q_e(obs, a) = w_e . a + b_e (zero hidden
+    kernels would kill the input, so one relu layer passes |a| through): the min over the ensemble and the argmax
+    over the candidates are computable by hand; the categorical draw is argmax(logits + Gumbel)."""
+    S, A, H_, E, B, N = 2, 2, 256, 2, 3, 5
+    p = orc.make_critic_params(S, A, (H_,), E, 0, dtype=np.float64, bias_std=0.0)
+    k0 = np.zeros((E, S + A, H_)); k1 = np.zeros((E, H_, 1)); b1 = np.zeros((E, 1))
+    # hidden unit 0 = relu(a_0), unit 1 = relu(-a_0): q_0 = |a_0| ... member 1 scores a_1 + 10
+    k0[:, S + 0, 0], k0[:, S + 0, 1] = 1.0, -1.0
+    k0[1, S + 1, 2], k0[1, S + 1, 3] = 1.0, -1.0
+    k1[0, 0, 0] = k1[0, 1, 0] = 1.0                       # member 0: |a_0|
+    k1[1, 2, 0], k1[1, 3, 0] = 1.0, -1.0; b1[1, 0] = 10.0  # member 1: a_1 + 10
+    p["base"]["backbone"]["Dense_0"]["kernel"] = k0
+    p["base"]["Dense_0"] = {"kernel": k1, "bias": b1}
+    rng = np.random.default_rng(3)
+    obs, act = rng.standard_normal((B, S)), rng.uniform(-1, 1, (B, N, A))
+    q = orc.critic_apply(p, np.repeat(obs[:, None], N, 1), act, 1, "relu")
+    assert q.shape == (E, B, N, 1)
+    np.testing.assert_allclose(q[0, ..., 0], np.abs(act[..., 0]), atol=1e-12)
+    np.testing.assert_allclose(q[1, ..., 0], act[..., 1] + 10.0, atol=1e-12)
+    chosen, idx, qs = orc.select_best(p, obs, act, 1, "relu", temperature=0.0)
+    np.testing.assert_allclose(qs, np.abs(act[..., 0]), atol=1e-12)           # |a_0| <= 1 < a_1 + 10: member 0 is the min
+    assert (idx == np.abs(act[..., 0]).argmax(-1)).all()
+    np.testing.assert_array_equal(chosen, act[np.arange(B), idx])
+    g = np.zeros((B, N)); g[:, 3] = 1e6                                       # overwhelming Gumbel noise picks candidate 3
+    assert (orc.select_best(p, obs, act, 1, "relu", temperature=1.0, gumbel=g)[1] == 3).all()
