@@ -175,44 +175,121 @@ def backbone_bwd(spec: orc.BackboneSpec, params: Dict, c, gout, grads: Dict):
 
 
 # ---- chain VJP --------------------------------------------------------------------------------------------
-def ddpm_sample_vjp(spec: orc.BackboneSpec, params: Dict, tables, xT, condition, noise, g, *, steps: int,
-                    solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None, xt_hist=None):
-    """d sum(g * x0) / d params and / d xT for DDPM.sample (ddpm.py:173-221).  float64 throughout.
-    ``xt_hist`` (T, ..., A), optional: take the input of iteration j from it instead of from the recomputed chain —
-    the product's VJP works from the forward call's history[0] the same way, so a reduced-precision variant can be
-    checked on identical chain states."""
+def _chain_vjp(spec, params, xT, condition, g, steps, step_fwd, xt_hist=None):
+    """Shared driver: ``step_fwd(j, xt, eps) -> (x_next, bwd)`` with ``bwd(g_next) -> (g_eps, g_xt_direct)``;
+    the time input of iteration j comes from ``step_fwd.tvals[j]``."""
     dt = np.float64
     params = orc.cast_tree(params, dt)
-    betas, alphas, alpha_hats, postvars = [np.asarray(a, dtype=dt) for a in tables]
     xt = np.asarray(xT, dt)
     cond = None if condition is None else np.asarray(condition, dt)
-    noise = np.asarray(noise, dt)
     fw = []
-    for j, t in enumerate(range(steps, 0, -1)):
+    for j in range(steps):
         if xt_hist is not None:
             xt = np.asarray(xt_hist[j], dt)
-        tin = np.full((*xt.shape[:-1], 1), float(t), dtype=dt)
+        tin = np.full((*xt.shape[:-1], 1), float(step_fwd.tvals[j]), dtype=dt)
         eps, cache = backbone_fwd(spec, params, xt, tin, cond)
-        ah, ah1, al = alpha_hats[t], alpha_hats[t - 1], alphas[t]
-        if solver == "ddpm":
-            c0, c1 = 1.0 / np.sqrt(ah), np.sqrt(1.0 - ah)
-            x0h = c0 * (xt - c1 * eps)
-            mask = np.ones_like(x0h)
-            if clip_sampler:
-                mask = ((x0h >= x_min) & (x0h <= x_max)).astype(dt)
-                x0h = np.clip(x0h, x_min, x_max)
-            c2, c3, c4 = 1.0 / (1.0 - ah), np.sqrt(ah1) * (1.0 - al), np.sqrt(al) * (1.0 - ah1)
-            xn = c2 * (c3 * x0h + c4 * xt) + float(t > 1) * np.sqrt(postvars[t]) * noise[j]
-            fw.append((cache, mask, (c0, c1, c2, c3, c4)))
-        else:
-            raise NotImplementedError(solver)
+        xn, bwd = step_fwd(j, xt, eps)
+        fw.append((cache, bwd))
         xt = xn
     x0 = xt
     grads: Dict = {}
     gx = np.asarray(g, dt)
     for j in reversed(range(steps)):
-        cache, mask, (c0, c1, c2, c3, c4) = fw[j]
-        g_x0h = c2 * c3 * gx * mask
-        geps = -c0 * c1 * g_x0h
-        gx = c2 * c4 * gx + c0 * g_x0h + backbone_bwd(spec, params, cache, geps, grads)
+        cache, bwd = fw[j]
+        g_eps, g_dir = bwd(gx)
+        gx = g_dir + backbone_bwd(spec, params, cache, g_eps, grads)
     return x0, grads, gx
+
+
+def _clip_mask(v, clip_sampler, x_min, x_max):
+    if not clip_sampler:
+        return v, np.ones_like(v)
+    return np.clip(v, x_min, x_max), ((v >= x_min) & (v <= x_max)).astype(np.float64)
+
+
+def ddpm_sample_vjp(spec: orc.BackboneSpec, params: Dict, tables, xT, condition, noise, g, *, steps: int,
+                    solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None, xt_hist=None):
+    """d sum(g * x0) / d params and / d xT for DDPM.sample (ddpm.py:173-221), solvers ddpm and ddim.  float64 throughout.
+    ``xt_hist`` (T, ..., A), optional: take the input of iteration j from it instead of from the recomputed chain —
+    the product's VJP works from the forward call's history[0] the same way, so a reduced-precision variant can be
+    checked on identical chain states."""
+    dt = np.float64
+    betas, alphas, alpha_hats, postvars = [np.asarray(a, dtype=dt) for a in tables]
+    noise = None if noise is None else np.asarray(noise, dt)
+
+    def step(j, xt, eps):
+        t = steps - j
+        ah, ah1, al = alpha_hats[t], alpha_hats[t - 1], alphas[t]
+        if solver == "ddpm":                                   # ddpm.py:198-206
+            c0, c1 = 1.0 / np.sqrt(ah), np.sqrt(1.0 - ah)
+            x0h, mask = _clip_mask(c0 * (xt - c1 * eps), clip_sampler, x_min, x_max)
+            c2, c3, c4 = 1.0 / (1.0 - ah), np.sqrt(ah1) * (1.0 - al), np.sqrt(al) * (1.0 - ah1)
+            xn = c2 * (c3 * x0h + c4 * xt) + float(t > 1) * np.sqrt(postvars[t]) * noise[j]
+
+            def bwd(gn):
+                g0 = c2 * c3 * gn * mask
+                return -c0 * c1 * g0, c2 * c4 * gn + c0 * g0
+        elif solver == "ddim":                                 # ddpm.py:207-213: clips xt_1, prefactor 1/sqrt(alpha_t)
+            a1, a2, a3 = 1.0 / np.sqrt(al), np.sqrt(1.0 - ah), np.sqrt(1.0 - ah1)
+            xn, mask = _clip_mask(a1 * (xt - a2 * eps) + a3 * eps, clip_sampler, x_min, x_max)
+
+            def bwd(gn):
+                gp = gn * mask
+                return gp * (a3 - a1 * a2), a1 * gp
+        else:
+            raise NotImplementedError(solver)
+        return xn, bwd
+
+    step.tvals = [float(steps - j) for j in range(steps)]
+    return _chain_vjp(spec, params, xT, condition, g, steps, step, xt_hist)
+
+
+def continuous_ddpm_sample_vjp(spec: orc.BackboneSpec, params: Dict, tables, xT, condition, noise, g, *, steps: int,
+                               solver: str = "ddpm", clip_sampler: bool = False, x_min=None, x_max=None, xt_hist=None):
+    """The same for ContinuousDDPM.sample (continuous_ddpm.py:159-177, solvers ddpm and ddim) — what DACER's actor loss
+    differentiates (agent/online/dacer.py:141-162).  ``tables`` = (ts, alpha_hats, alphas, betas)."""
+    dt = np.float64
+    ts, alpha_hats, alphas, betas = [np.asarray(a, dtype=dt) for a in tables]
+    noise = None if noise is None else np.asarray(noise, dt)
+
+    def step(j, xt, eps):
+        i = steps - j
+        ah, ah1, al, be = alpha_hats[i], alpha_hats[i - 1], alphas[i], betas[i]
+        c0, c1 = np.sqrt(ah), np.sqrt(1.0 - ah)
+        x0h, mask = _clip_mask((xt - c1 * eps) / c0, clip_sampler, x_min, x_max)
+        if solver == "ddpm":
+            m1, m2 = np.sqrt(ah1) * be / (1.0 - ah), np.sqrt(al) * (1.0 - ah1) / (1.0 - ah)
+            xn = m1 * x0h + m2 * xt + float(i > 1) * np.sqrt(be) * noise[j]
+
+            def bwd(gn):
+                g0 = m1 * gn * mask
+                return -(c1 / c0) * g0, m2 * gn + g0 / c0
+        elif solver == "ddim":
+            m1, m2 = np.sqrt(ah1), np.sqrt(1.0 - ah1)
+            xn = m1 * x0h + m2 * eps
+
+            def bwd(gn):
+                g0 = m1 * gn * mask
+                return -(c1 / c0) * g0 + m2 * gn, g0 / c0
+        else:
+            raise NotImplementedError(solver)
+        return xn, bwd
+
+    step.tvals = [float(ts[steps - j]) for j in range(steps)]
+    return _chain_vjp(spec, params, xT, condition, g, steps, step, xt_hist)
+
+
+def cnf_sample_vjp(spec: orc.BackboneSpec, params: Dict, x0, condition, g, *, steps: int, clip_sampler: bool = False,
+                   x_min=None, x_max=None, xt_hist=None):
+    """The same for ContinuousNormalizingFlow.sample (cnf.py:92-141): x_next = clip(xt + vel / steps)."""
+    def step(j, xt, vel):
+        xn, mask = _clip_mask(xt + vel / float(steps), clip_sampler, x_min, x_max)
+
+        def bwd(gn):
+            gp = gn * mask
+            return gp / float(steps), gp
+        return xn, bwd
+
+    # step2t(arange(steps)) in float32 (cnf.py:80-83), as the product computes it
+    step.tvals = [float(np.float32(j) / np.float32(steps)) for j in range(steps)]
+    return _chain_vjp(spec, params, x0, condition, g, steps, step, xt_hist)
