@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import _lib
-from .._sampler import run_sampler
+from .._sampler import run_sampler, run_sampler_vjp
 from ..module import FlowBackbone, init_params
 
 
@@ -46,3 +46,16 @@ class ContinuousNormalizingFlow:
             condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
             x_max=self.x_max, history=history, particles=particles, compute_dtype=compute_dtype)
         return rng, x1, hist
+
+    def sample_vjp(self, xt_hist: torch.Tensor, g_x1: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                   params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gx0: bool = True,
+                   compute_dtype: str = "f32"):
+        """VJP of :meth:`sample` w.r.t. the parameter tree and x0 (what ``jax.grad`` through the unrolled Euler scan
+        cnf.py:122-141 computes), from history[0] of the forward call and dL/dx1."""
+        p = params if params is not None else self.params
+        # step2t(arange(steps)), cnf.py:80-83: float32 k / steps
+        tvals = (torch.arange(self.steps, dtype=torch.float32) / torch.tensor(float(self.steps), dtype=torch.float32)).to(torch.float64)
+        return run_sampler_vjp(
+            self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xt_hist=xt_hist,
+            condition=condition, g_x0=g_x1, sched={}, tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
+            x_max=self.x_max, particles=particles, want_gxT=want_gx0, compute_dtype=compute_dtype)

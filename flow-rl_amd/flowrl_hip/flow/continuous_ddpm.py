@@ -9,7 +9,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from .. import _lib, schedules
-from .._sampler import run_sampler
+from .._sampler import run_sampler, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
 from .ddpm import draw_noise
 
@@ -81,3 +81,27 @@ class ContinuousDDPM:
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
             particles=particles, compute_dtype=compute_dtype)
         return rng, x0, hist
+
+    def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                   solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
+                   params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gxT: bool = True,
+                   compute_dtype: str = "f32"):
+        """VJP of :meth:`sample` (solvers ddpm / ddim) w.r.t. the parameter tree and xT — what DACER's actor loss
+        differentiates (agent/online/dacer.py:141-162: jax.grad through continuous_ddpm.py:159-220), from history[0] of the
+        forward call and dL/dx0."""
+        steps = steps or self.steps
+        t_schedule_n = t_schedule_n or self.t_schedule_n
+        solver = solver or self.solver
+        if solver not in ("ddpm", "ddim"):
+            raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, f"solver {solver} has no backward kernel (ddpm / ddim)")
+        ts, ah, al, be = schedules.continuous_tables(steps, self.noise_schedule_func, self.t_diffusion, t_schedule_n)
+        dev = g_x0.device
+        to = lambda v: torch.from_numpy(v).to(dev)
+        p = params if params is not None else self.params
+        tvals = torch.from_numpy(ts[::-1][:steps].copy()).to(torch.float64)          # iteration j <-> ts[steps - j]
+        return run_sampler_vjp(
+            self.network, p, kind=_lib.FRL_KIND_CDDPM,
+            solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM, steps=steps, xt_hist=xt_hist,
+            condition=condition, g_x0=g_x0, sched={"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)},
+            tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, particles=particles,
+            want_gxT=want_gxT, compute_dtype=compute_dtype)

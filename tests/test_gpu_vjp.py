@@ -28,24 +28,47 @@ def _flatten(tree, prefix=""):
     return out
 
 
-def _run(case):
-    import torch
+def oracle_vjp(case, params, xT, cond, noise, g, xt_hist=None):
+    """float64 oracle VJP of the case's sampler: (x0, grads tree, dL/dxT)."""
     import flowrl_oracle_vjp as ov
     import flowrl_oracle as orc
+    cd = None if cond is None else np.repeat(cond, case.particles, axis=0)
+    kw = dict(steps=case.T, clip_sampler=case.clip, x_min=case.x_min, x_max=case.x_max, xt_hist=xt_hist)
+    if case.kind == "ddpm":
+        tables = orc.ddpm_tables(case.T, case.schedule, approx_postvar=case.approx_postvar, dtype=np.float32)
+        return ov.ddpm_sample_vjp(case.spec, params, tables, xT, cd, noise, g, solver=case.solver, **kw)
+    if case.kind == "cddpm":
+        tables = orc.continuous_tables(case.T, case.schedule, dtype=np.float32)
+        return ov.continuous_ddpm_sample_vjp(case.spec, params, tables, xT, cd, noise, g, solver=case.solver, **kw)
+    return ov.cnf_sample_vjp(case.spec, params, xT, cd, g, **kw)
+
+
+def product_vjp(case, model, xT, cond, noise, g, compute_dtype="f32"):
+    """Forward with history + VJP through the product; returns (grads tree, dL/dxT, xt_hist) as torch tensors."""
+    import torch
+    x = torch.from_numpy(xT).cuda()
+    c = None if cond is None else torch.from_numpy(cond).cuda()
+    gt = torch.from_numpy(g).cuda()
+    parts = case.particles if case.particles > 1 else None
+    kw = dict(history=True, particles=parts, params=model.params, compute_dtype=compute_dtype)
+    if case.kind == "cnf":
+        _, x0, (xh, _) = model.sample(None, x, c, True, **kw)
+        grads, gxT = model.sample_vjp(xh, gt, c, particles=parts, compute_dtype=compute_dtype)
+    else:
+        nz = torch.from_numpy(noise).cuda() if case.solver == "ddpm" else None
+        _, x0, (xh, _) = model.sample(None, x, c, True, case.solver, noise=nz, **kw)
+        grads, gxT = model.sample_vjp(xh, gt, c, case.solver, particles=parts, compute_dtype=compute_dtype)
+    return grads, gxT, xh
+
+
+def _run(case):
+    import torch
     params, xT, cond, noise = H.make_inputs(case)
     rng = np.random.default_rng(77 + case.seed)
     g = rng.standard_normal((case.B, case.A)).astype(np.float32)
-    tables = orc.ddpm_tables(case.T, case.schedule, approx_postvar=case.approx_postvar, dtype=np.float32)
-    cd = None if cond is None else np.repeat(cond, case.particles, axis=0)
-    x0_ref, gref, gx_ref = ov.ddpm_sample_vjp(case.spec, params, tables, xT, cd, noise, g, steps=case.T, solver=case.solver,
-                                              clip_sampler=case.clip, x_min=case.x_min, x_max=case.x_max)
+    x0_ref, gref, gx_ref = oracle_vjp(case, params, xT, cond, noise, g)
     model = H.product_model(case, params)
-    x = torch.from_numpy(xT).cuda()
-    c = None if cond is None else torch.from_numpy(cond).cuda()
-    parts = case.particles if case.particles > 1 else None
-    _, x0, (xh, _) = model.sample(None, x, c, True, case.solver, noise=torch.from_numpy(noise).cuda(), history=True,
-                                  particles=parts, params=model.params)
-    grads, gxT = model.sample_vjp(xh, torch.from_numpy(g).cuda(), c, case.solver, particles=parts)
+    grads, gxT, _ = product_vjp(case, model, xT, cond, noise, g)
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in _flatten(grads).items()}
     ref = _flatten(gref)
@@ -75,6 +98,13 @@ CASES = [
     H.Case("one_hidden_nocond", "ddpm", A=2, S=0, T=6, B=64, hidden=(256,), clip=False, seed=6),
     H.Case("raw_time", "ddpm", A=3, S=11, T=5, B=64, temb=None, seed=7),
     H.Case("multi_tile", "ddpm", A=3, S=11, T=5, B=20000, seed=8),
+    # the other update rules the sweep knows (DACER differentiates ContinuousDDPM.sample, dacer.py:141-162)
+    H.Case("ddpm_ddim", "ddpm", A=3, S=11, T=5, B=96, solver="ddim", seed=9),
+    H.Case("cddpm_cosine", "cddpm", A=6, S=17, T=20, B=64, temb="learnable_fourier", schedule="cosine", seed=10),
+    H.Case("cddpm_ddim_noclip", "cddpm", A=3, S=11, T=8, B=70, temb="learnable_fourier", schedule="cosine", solver="ddim",
+           clip=False, seed=11),
+    H.Case("cnf_raw_t", "cnf", A=8, S=20, T=10, B=64, temb=None, clip=False, seed=12),
+    H.Case("cnf_clip_positional", "cnf", A=3, S=11, T=6, B=40, clip=True, act="silu", seed=13),
 ]
 
 

@@ -50,12 +50,8 @@ def _rel_l2(got, ref):
 
 
 def _oracle(case, params, xT, cond, noise, g, xt_hist=None):
-    import flowrl_oracle as orc
-    import flowrl_oracle_vjp as ov
-    tables = orc.ddpm_tables(case.T, case.schedule, approx_postvar=case.approx_postvar, dtype=np.float32)
-    cd = None if cond is None else np.repeat(cond, case.particles, axis=0)
-    _, gref, gx = ov.ddpm_sample_vjp(case.spec, params, tables, xT, cd, noise, g, steps=case.T, solver=case.solver,
-                                     clip_sampler=case.clip, x_min=case.x_min, x_max=case.x_max, xt_hist=xt_hist)
+    from test_gpu_vjp import oracle_vjp
+    _, gref, gx = oracle_vjp(case, params, xT, cond, noise, g, xt_hist=xt_hist)
     out = _flatten(gref)
     out["dL/dxT"] = gx
     return out
@@ -63,16 +59,12 @@ def _oracle(case, params, xT, cond, noise, g, xt_hist=None):
 
 def _run(case):
     import torch
+    from test_gpu_vjp import product_vjp
     assert case.bf16
     params, xT, cond, noise = H.make_inputs(case)
     g = np.random.default_rng(77 + case.seed).standard_normal((case.B, case.A)).astype(np.float32)
     model = H.product_model(case, params)
-    x = torch.from_numpy(xT).cuda()
-    c = None if cond is None else torch.from_numpy(cond).cuda()
-    parts = case.particles if case.particles > 1 else None
-    _, x0, (xh, _) = model.sample(None, x, c, True, case.solver, noise=torch.from_numpy(noise).cuda(), history=True,
-                                  particles=parts, params=model.params, compute_dtype="bf16")
-    grads, gxT = model.sample_vjp(xh, torch.from_numpy(g).cuda(), c, case.solver, particles=parts, compute_dtype="bf16")
+    grads, gxT, xh = product_vjp(case, model, xT, cond, noise, g, compute_dtype="bf16")
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in _flatten(grads).items()}
     got["dL/dxT"] = gxT.cpu().numpy()
@@ -108,6 +100,8 @@ CASES = [
     H.Case("one_hidden_nocond", "ddpm", A=2, S=0, T=6, B=64, hidden=(256,), clip=False, seed=6, bf16=True),
     H.Case("raw_time", "ddpm", A=3, S=11, T=5, B=64, temb=None, schedule="linear", seed=7, bf16=True),
     H.Case("multi_tile", "ddpm", A=3, S=11, T=5, B=20000, clip=False, seed=8, bf16=True),
+    H.Case("cddpm_cosine", "cddpm", A=6, S=17, T=20, B=64, temb="learnable_fourier", schedule="cosine", clip=False, seed=10, bf16=True),
+    H.Case("cnf_raw_t", "cnf", A=8, S=20, T=10, B=64, temb=None, clip=False, seed=12, bf16=True),
 ]
 
 

@@ -80,3 +80,51 @@ def test_vjp_matches_torch_autograd_with_clip():
     for name, gv in orc.flatten_tree(grads).items():
         np.testing.assert_allclose(gv, tp[name].grad.numpy(), rtol=1e-8, atol=1e-10, err_msg=name)
     np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("kind,solver,clip", [("ddpm", "ddim", False), ("cddpm", "ddpm", False), ("cddpm", "ddim", False),
+                                               ("cnf", "euler", False), ("cddpm", "ddpm", True)])
+def test_vjp_other_samplers_match_finite_differences(kind, solver, clip):
+    """ddim, ContinuousDDPM (what DACER differentiates, dacer.py:141-162) and CNF Euler: the same finite-difference pin."""
+    temb = None if kind == "cnf" else "learnable_fourier"
+    spec, params, tabs, xT, cond, noise, g, kw = _setup(act="mish", temb=temb, clip=clip)
+    T = kw["steps"]
+    if kind == "ddpm":
+        fwd = lambda p, x: orc.ddpm_sample(spec, p, tabs, x, cond, noise, solver=solver, **kw)[0]
+        x0, grads, gx = ov.ddpm_sample_vjp(spec, params, tabs, xT, cond, noise, g, solver=solver, **kw)
+    elif kind == "cddpm":
+        ctabs = [t.astype(np.float64) for t in orc.continuous_tables(T, "cosine")]
+        fwd = lambda p, x: orc.continuous_ddpm_sample(spec, p, ctabs, x, cond, noise, solver=solver, **kw)[0]
+        x0, grads, gx = ov.continuous_ddpm_sample_vjp(spec, params, ctabs, xT, cond, noise, g, solver=solver, **kw)
+    else:
+        spec = orc.BackboneSpec(hidden_dims=[32, 32], x_dim=3, activation="mish", time_embedding=None, time_dim=16,
+                                predictor_name="vel_predictor")
+        params = orc.cast_tree(orc.make_params(spec, 5, seed=0), np.float64)
+        fwd = lambda p, x: orc.cnf_sample(spec, p, x, cond, **kw)[0]
+        x0, grads, gx = ov.cnf_sample_vjp(spec, params, xT, cond, g, **kw)
+    np.testing.assert_allclose(x0, fwd(params, xT), rtol=1e-6, atol=1e-7)     # (cnf: float32 time grid vs float64)
+    flat, gflat = orc.flatten_tree(params), orc.flatten_tree(grads)
+    assert set(flat) == set(gflat)
+    rng = np.random.default_rng(7)
+    h = 1e-6
+    tol = 2e-5 if clip else 2e-6          # a finite-difference stencil may straddle a clip boundary
+    bad = 0
+    for name, arr in flat.items():
+        for _ in range(2):
+            idx = tuple(rng.integers(0, s) for s in arr.shape)
+            old = arr[idx]
+            arr[idx] = old + h
+            lp = float(np.sum(g * fwd(orc.unflatten_tree(flat), xT)))
+            arr[idx] = old - h
+            lm = float(np.sum(g * fwd(orc.unflatten_tree(flat), xT)))
+            arr[idx] = old
+            fd = (lp - lm) / (2 * h)
+            ok = abs(fd - gflat[name][idx]) <= tol * max(1.0, abs(fd))
+            bad += not ok
+            assert ok or clip, (name, idx, fd, gflat[name][idx])
+    assert bad <= 1
+    xp, xm = xT.copy(), xT.copy()
+    xp[1, 2] += h
+    xm[1, 2] -= h
+    fd = (float(np.sum(g * fwd(params, xp))) - float(np.sum(g * fwd(params, xm)))) / (2 * h)
+    assert abs(fd - gx[1, 2]) <= tol * max(1.0, abs(fd))
