@@ -333,7 +333,26 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   b.grad_tb = bufs->grad_tb;
   b.Dp = Dp;
   b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
-  return bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stream);
+  rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stream);
+  if (rc != FRL_OK) return rc;
+  const bool native_time = (desc->time_embed == FRL_TEMB_NONE) ? (bufs->grad_bias[0] != nullptr) : (bufs->grad_tmlp_kernel[0] != nullptr);
+  if (!native_time) return FRL_OK;
+  if (desc->time_embed != FRL_TEMB_NONE) {
+    if (bufs->grad_tmlp_kernel[1] == nullptr || bufs->grad_tmlp_bias[0] == nullptr || bufs->grad_tmlp_bias[1] == nullptr || bufs->grad_bias[0] == nullptr) {
+      set_error("bufs.grad_tmlp_kernel / grad_tmlp_bias / grad_bias[0]: all or none"); return FRL_EINVAL; }
+    if (desc->time_embed == FRL_TEMB_FOURIER && bufs->grad_time_kernel == nullptr) { set_error("bufs.grad_time_kernel is NULL"); return FRL_EINVAL; }
+  }
+  TBArgs tb;
+  memset(&tb, 0, sizeof(tb));
+  tb.p = *params;
+  if (sched != nullptr) tb.s = *sched;
+  tb.grad_tb = bufs->grad_tb;
+  tb.scratch = (double*)(ws + (bf16 ? bp16.off_tbs : bp.off_tbs));
+  for (int k = 0; k < 2; ++k) { tb.g_tmlp_kernel[k] = bufs->grad_tmlp_kernel[k]; tb.g_tmlp_bias[k] = bufs->grad_tmlp_bias[k]; }
+  tb.g_time_kernel = bufs->grad_time_kernel;
+  tb.g_bias0 = bufs->grad_bias[0]; tb.g_kernel0 = bufs->grad_kernel[0];
+  tb.kind = desc->kind; tb.time_embed = desc->time_embed; tb.T = pl.T; tb.D = pl.D; tb.H = pl.H; tb.A = pl.A;
+  return launch_time_bwd(tb, stream);
 }
 
 // ---- critic scoring + best-of-N selection ------------------------------------------------------

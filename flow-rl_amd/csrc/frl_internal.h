@@ -149,6 +149,9 @@ struct PArgs {
   int kind, time_embed;
 };
 
+// double scratch (counted in floats) of the time-branch VJP kernel (csrc/time_bwd.hip): (1 + 7 D) T doubles
+inline size_t time_bwd_scratch_floats(int T, int D) { return 2 * ((size_t)T * (1 + 7 * (size_t)(D > 0 ? D : 0)) + 8); }
+
 // ---- backward (chain VJP) -------------------------------------------------------------------------------
 // Workspace of frl_sampler_bwd = the forward tables (Plan) followed by transposed / packed weight images and the
 // per-(wave-tile, step, layer) stash [64 register pairs][64 lanes][2] f32 = 32 KB each:
@@ -163,6 +166,7 @@ struct BwdPlan {
   size_t off_w0xq;               // per-lane packed image of Dense_0's x rows (A operand of dx = W0x G_0)
   size_t off_hd, off_ad, off_gd; // stash, n_ts * L * 8192 floats each
   size_t off_ge;                 // dL/deps per tile-step: [NRX=4 regs][64 lanes]
+  size_t off_tbs;                // double scratch of the time-branch VJP
   size_t total_floats;
 };
 
@@ -180,6 +184,7 @@ inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
   b.off_ad = take((size_t)b.n_ts * p.L * 8192);
   b.off_gd = take((size_t)b.n_ts * p.L * 8192);
   b.off_ge = take((size_t)b.n_ts * 256);
+  b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
   b.total_floats = o;
   return 0;
 }
@@ -205,7 +210,7 @@ struct BArgs {
 struct BwdPlan16 {
   Plan f;
   long long n_wt, n_ts;
-  size_t off_img_b, off_hd, off_ad, off_gd, off_ge, total_floats;
+  size_t off_img_b, off_hd, off_ad, off_gd, off_ge, off_tbs, total_floats;
 };
 
 inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
@@ -220,12 +225,25 @@ inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
   b.off_ad = take((size_t)b.n_ts * p.L * 4096);
   b.off_gd = take((size_t)b.n_ts * p.L * 4096);
   b.off_ge = take((size_t)b.n_ts * 256);
+  b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
   b.total_floats = o;
   return 0;
 }
 
 int launch_prepare_bwd_bf16(const FrlParams& p, const BwdPlan16& bp, float* ws, hipStream_t stream);
 int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& a, hipStream_t stream);
+
+// time-branch VJP (csrc/time_bwd.hip): one workgroup, double-precision scratch of (1 + 7 D) T doubles
+struct TBArgs {
+  FrlParams p;
+  FrlSchedule s;
+  const float* grad_tb;
+  double* scratch;
+  float* g_tmlp_kernel[2]; float* g_tmlp_bias[2]; float* g_time_kernel;
+  float* g_bias0; float* g_kernel0;      // Dense_0 bias; Dense_0 kernel (rows [A, A + D') are written)
+  int kind, time_embed, T, D, H, A;
+};
+int launch_time_bwd(const TBArgs& a, hipStream_t stream);
 
 int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
 int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, hipStream_t stream);

@@ -53,7 +53,8 @@ class FrlFwdBufs(C.Structure):
 
 class FrlBwdBufs(C.Structure):
     _fields_ = [("xt_hist", _fp), ("cond", _fp), ("g_x0", _fp), ("g_xT", _fp),
-                ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_tb", _fp)]
+                ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_tb", _fp),
+                ("grad_tmlp_kernel", _fp * 2), ("grad_tmlp_bias", _fp * 2), ("grad_time_kernel", _fp)]
 
 
 class FrlCriticDesc(C.Structure):

@@ -241,58 +241,13 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
 
 
 # ---- chain VJP -----------------------------------------------------------------------------------------------
-def _mish64(x):
-    return x * torch.tanh(torch.nn.functional.softplus(x))
-
-
-def time_branch_vjp(network, params: Dict, tvals: torch.Tensor, grad_tb: torch.Tensor, x_dim: int) -> Dict:
-    """Gradients of everything that feeds the hoisted bias table tb[j] = bias_0 + tfeat(t_j) @ kernel_0[A:A+D']
-    (ddpm.py:84-91: time_embedding -> MLP_0 (mish, mish) -> concat slice of Dense_0), given dL/dtb from the kernel.
-    Batch-invariant, O(T D^2): a handful of (T, D) float64 matrix ops on the device, differentiated with autograd.
-    Returns a partial grads tree (float32): MLP_0, time_embedding, and the predictor's Dense_0 bias / time rows."""
-    te = network.time_embedding
-    pname = network.predictor_name
-    f64 = torch.float64
-    g = grad_tb.to(f64)
-    W0 = params[pname]["Dense_0"]["kernel"]
-    t = tvals.to(f64).reshape(-1, 1)
-    out: Dict = {pname: {"Dense_0": {"bias": g.sum(0).to(torch.float32)}}}
-    if te is None:
-        out[pname]["Dense_0"]["time_rows"] = (t.T @ g).to(torch.float32)
-        return out
-    D = te.output_dim
-    leaves = {("MLP_0", f"Dense_{i}", n): params["MLP_0"][f"Dense_{i}"][n].detach().to(f64).requires_grad_(True)
-              for i in range(2) for n in ("kernel", "bias")}
-    if isinstance(te, LearnableFourierEmbedding):
-        wk = params["time_embedding"]["kernel"].detach().to(f64).requires_grad_(True)
-        leaves[("time_embedding", "kernel")] = wk
-        f = 2.0 * torch.pi * t @ wk.T                                     # time_embedding.py:23-27
-    else:
-        half = D // 2
-        fr = torch.exp(torch.arange(half, dtype=f64, device=t.device) * -(torch.log(torch.tensor(10000.0, dtype=f64)) / (half - 1)))
-        f = t * fr                                                        # time_embedding.py:11-16
-    temb = torch.cat([torch.cos(f), torch.sin(f)], dim=-1)
-    h = _mish64(temb @ leaves[("MLP_0", "Dense_0", "kernel")] + leaves[("MLP_0", "Dense_0", "bias")])
-    tfeat = _mish64(h @ leaves[("MLP_0", "Dense_1", "kernel")] + leaves[("MLP_0", "Dense_1", "bias")])
-    wt = W0[x_dim:x_dim + D].detach().to(f64).requires_grad_(True)
-    keys = list(leaves)
-    grads = torch.autograd.grad(tfeat @ wt, [leaves[k] for k in keys] + [wt], grad_outputs=g)
-    for k, gv in zip(keys, grads[:-1]):
-        node = out
-        for name in k[:-1]:
-            node = node.setdefault(name, {})
-        node[k[-1]] = gv.to(torch.float32)
-    out[pname]["Dense_0"]["time_rows"] = grads[-1].to(torch.float32)
-    return out
-
-
 def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int, xt_hist: torch.Tensor,
                     condition: Optional[torch.Tensor], g_x0: torch.Tensor, sched: Dict[str, torch.Tensor],
-                    tvals: torch.Tensor, clip_sampler: bool, x_min, x_max, particles: Optional[int] = None,
+                    tvals: Optional[torch.Tensor] = None, clip_sampler: bool = False, x_min=None, x_max=None, particles: Optional[int] = None,
                     want_gxT: bool = True, compute_dtype: str = "f32"):
-    """dL/dparams (Flax-layout tree) and dL/dxT of one sampler call, given its history[0] and dL/dx0.
-    The O(B) work (recompute + backward sweep + weight-gradient GEMMs) is libflowrl_hip's frl_sampler_bwd; the
-    batch-invariant time branch is finished here from the kernel's dL/dtb (see :func:`time_branch_vjp`)."""
+    """dL/dparams (Flax-layout tree) and dL/dxT of one sampler call, given its history[0] and dL/dx0.  Everything is
+    libflowrl_hip's frl_sampler_bwd: recompute + backward sweep + weight-gradient GEMMs (O(B)), and the batch-invariant
+    time branch (MLP_0, time_embedding, Dense_0's bias and time rows) from the kernel's own dL/dtb."""
     lib = _lib.load()
     if not g_x0.is_cuda:
         raise RuntimeError("flowrl_hip VJP runs on the GPU only; there is no CPU fallback")
@@ -326,6 +281,19 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
         bufs.grad_kernel[i], bufs.grad_bias[i] = gk.data_ptr(), gb.data_ptr()
     grad_tb = torch.empty((steps, H), dtype=torch.float32, device=device)
     bufs.grad_tb = grad_tb.data_ptr()
+    te = network.time_embedding
+    if te is not None:      # the library finishes the time branch: MLP_0 leaves (+ the Fourier kernel)
+        grads["MLP_0"] = {}
+        for i in range(2):
+            k = params["MLP_0"][f"Dense_{i}"]
+            gk = torch.empty_like(k["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
+            gb = torch.empty_like(k["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
+            grads["MLP_0"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
+            bufs.grad_tmlp_kernel[i], bufs.grad_tmlp_bias[i] = gk.data_ptr(), gb.data_ptr()
+        if isinstance(te, LearnableFourierEmbedding):
+            gw = torch.empty_like(params["time_embedding"]["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
+            grads["time_embedding"] = {"kernel": gw}
+            bufs.grad_time_kernel = gw.data_ptr()
 
     need = lib.frl_bwd_workspace_bytes(C.byref(desc))
     if need == 0:   # invalid / unsupported descriptor: let the entry point say why
@@ -337,13 +305,4 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
         rc = lib.frl_sampler_bwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs),
                                  ws.data_ptr(), ws.numel(), stream)
     _lib.check(rc)
-    # time branch (batch-invariant) from dL/dtb
-    tb = time_branch_vjp(network, params, tvals.to(device), grad_tb, A)
-    d0 = grads[pname]["Dense_0"]
-    d0["bias"].copy_(tb[pname]["Dense_0"]["bias"])
-    Dp = 1 if network.time_embedding is None else network.time_embedding.output_dim
-    d0["kernel"][A:A + Dp].copy_(tb[pname]["Dense_0"]["time_rows"])
-    for key in ("MLP_0", "time_embedding"):
-        if key in tb:
-            grads[key] = tb[key]
     return grads, (g_xT.reshape(*lead, A) if g_xT is not None else None)

@@ -160,8 +160,9 @@ int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
 
 /* ---- chain VJP (DQL-style backprop through the sampler: dql.py:93-123 -> jax.grad through ddpm.py:186-219) ----
  * Given the forward's history xt_hist (want_history = 1) and the cotangent g_x0 = dL/dx0, computes dL/d(params) of the
- * predictor MLP and dL/dxT.  The batch-invariant time branch is differentiated by the caller from grad_tb
- * (dL/d(tb), tb[j] = bias_0 + tfeat[j] @ kernel_0[A:A+D']): its gradients are O(T * D^2) work.
+ * predictor MLP and dL/dxT.  The batch-invariant time branch (O(T * D^2) work) hangs off grad_tb
+ * (dL/d(tb), tb[j] = bias_0 + tfeat[j] @ kernel_0[A:A+D']): either the caller differentiates it from grad_tb (a JAX
+ * binding gets that from jax.vjp of its own tfeat function) or the library does, see the optional outputs below.
  * This build: DDPM / ContinuousDDPM / CNF update rules, 256-wide predictor, mish / silu / relu, x_dim <= 8
  * (FRL_DTYPE_F32) or <= 16 (FRL_DTYPE_BF16: bf16 operands in every contraction, f32 accumulation),
  * x_dim + cond_dim <= 32, no cond_embedding; everything else returns FRL_EUNSUPPORTED. */
@@ -174,6 +175,13 @@ typedef struct FrlBwdBufs {
                                              Rows [A, A+D') of Dense_0 (time rows) are left zero: see grad_tb */
   float* grad_bias[FRL_MAX_HIDDEN + 1];   /* dL/d Dense_i bias for i >= 1; bias_0 comes from grad_tb (sum over steps) */
   float* grad_tb;       /* (T, H) dL/d(tb)                                                                */
+  /* Optional, all-or-none: when grad_tmlp_kernel[0] is non-NULL the library also finishes the time branch natively
+   * (one small double-precision kernel): dL/d MLP_0/Dense_{0,1} kernel (D, D) and bias (D,), dL/d
+   * time_embedding/kernel (D/2, 1) (FRL_TEMB_FOURIER; NULL otherwise), and then ALSO writes grad_bias[0] (H,) and
+   * the time rows [A, A + D') of grad_kernel[0].  With FRL_TEMB_NONE set grad_bias[0] to get the raw-time row. */
+  float* grad_tmlp_kernel[2];
+  float* grad_tmlp_bias[2];
+  float* grad_time_kernel;
 } FrlBwdBufs;
 
 size_t frl_bwd_workspace_bytes(const FrlDesc* desc);

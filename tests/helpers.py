@@ -129,3 +129,54 @@ def rms_err(got, ref):
         return 0.0
     d = (np.asarray(got, dtype=np.float64) - ref) / np.maximum(np.abs(ref), 1.0)
     return float(np.sqrt(np.mean(d * d)))
+
+
+# ---- independent torch-autograd restatement of the time-branch VJP (cross-check of csrc/time_bwd.hip) ----
+def _mish64(x):
+    import torch
+    return x * torch.tanh(torch.nn.functional.softplus(x))
+
+
+def torch_time_branch_vjp(network, params, tvals, grad_tb, x_dim):
+    """Gradients of everything that feeds the hoisted bias table tb[j] = bias_0 + tfeat(t_j) @ kernel_0[A:A+D']
+    (ddpm.py:84-91: time_embedding -> MLP_0 (mish, mish) -> concat slice of Dense_0), given dL/dtb from the kernel.
+    Batch-invariant, O(T D^2): a handful of (T, D) float64 matrix ops on the device, differentiated with autograd.
+    Returns a partial grads tree (float32): MLP_0, time_embedding, and the predictor's Dense_0 bias / time rows."""
+    import torch
+    from flowrl_hip.module import LearnableFourierEmbedding
+    te = network.time_embedding
+    pname = network.predictor_name
+    f64 = torch.float64
+    g = grad_tb.to(f64)
+    W0 = params[pname]["Dense_0"]["kernel"]
+    t = tvals.to(f64).reshape(-1, 1)
+    out: Dict = {pname: {"Dense_0": {"bias": g.sum(0).to(torch.float32)}}}
+    if te is None:
+        out[pname]["Dense_0"]["time_rows"] = (t.T @ g).to(torch.float32)
+        return out
+    D = te.output_dim
+    leaves = {("MLP_0", f"Dense_{i}", n): params["MLP_0"][f"Dense_{i}"][n].detach().to(f64).requires_grad_(True)
+              for i in range(2) for n in ("kernel", "bias")}
+    if isinstance(te, LearnableFourierEmbedding):
+        wk = params["time_embedding"]["kernel"].detach().to(f64).requires_grad_(True)
+        leaves[("time_embedding", "kernel")] = wk
+        f = 2.0 * torch.pi * t @ wk.T                                     # time_embedding.py:23-27
+    else:
+        half = D // 2
+        fr = torch.exp(torch.arange(half, dtype=f64, device=t.device) * -(torch.log(torch.tensor(10000.0, dtype=f64)) / (half - 1)))
+        f = t * fr                                                        # time_embedding.py:11-16
+    temb = torch.cat([torch.cos(f), torch.sin(f)], dim=-1)
+    h = _mish64(temb @ leaves[("MLP_0", "Dense_0", "kernel")] + leaves[("MLP_0", "Dense_0", "bias")])
+    tfeat = _mish64(h @ leaves[("MLP_0", "Dense_1", "kernel")] + leaves[("MLP_0", "Dense_1", "bias")])
+    wt = W0[x_dim:x_dim + D].detach().to(f64).requires_grad_(True)
+    keys = list(leaves)
+    grads = torch.autograd.grad(tfeat @ wt, [leaves[k] for k in keys] + [wt], grad_outputs=g)
+    for k, gv in zip(keys, grads[:-1]):
+        node = out
+        for name in k[:-1]:
+            node = node.setdefault(name, {})
+        node[k[-1]] = gv.to(torch.float32)
+    out[pname]["Dense_0"]["time_rows"] = grads[-1].to(torch.float32)
+    return out
+
+
