@@ -356,16 +356,19 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
 }
 
 // ---- critic scoring + best-of-N selection ------------------------------------------------------
-static int critic_plan(const FrlCriticDesc* c, FrlDesc& d, Plan& pl) {
+static int critic_plan(const FrlCriticDesc* c, FrlDesc& d, Plan& pl, bool& hoist) {
   if (c == nullptr) { set_error("critic desc is NULL"); return FRL_EINVAL; }
   if (c->abi_version != FRL_ABI_VERSION) { set_error("critic desc.abi_version %d != library %d", c->abi_version, FRL_ABI_VERSION); return FRL_EINVAL; }
   if (c->ensemble < 1 || c->ensemble > 16) { set_error("ensemble %d outside [1, 16]", c->ensemble); return FRL_EINVAL; }
   if (c->act_dim < 1 || c->obs_dim < 0) { set_error("act_dim %d / obs_dim %d invalid", c->act_dim, c->obs_dim); return FRL_EINVAL; }
+  // The observation rows of Dense_0 are the same for every candidate of a state: with several candidates per state (or
+  // an observation wider than the kernel's condition operand budget) they are hoisted into a per-state accumulator init.
+  hoist = c->obs_dim > 0 && (c->particles > 1 || c->obs_dim > 32);
   memset(&d, 0, sizeof(d));
   d.abi_version = FRL_ABI_VERSION;
   d.kind = FRL_KIND_CNF; d.solver = FRL_SOLVER_EULER; d.steps = 1;      // carrier only: the mode is overridden below
   d.n_states = c->n_states; d.particles = c->particles;
-  d.x_dim = c->act_dim; d.cond_dim = c->obs_dim;
+  d.x_dim = c->act_dim; d.cond_dim = hoist ? 0 : c->obs_dim;
   d.time_embed = FRL_TEMB_NONE; d.time_dim = 0;
   d.n_hidden = c->n_hidden;
   for (int l = 0; l < FRL_MAX_HIDDEN; ++l) d.hidden[l] = (l < c->n_hidden) ? c->hidden[l] : 0;
@@ -375,27 +378,33 @@ static int critic_plan(const FrlCriticDesc* c, FrlDesc& d, Plan& pl) {
   // ScalarCritic: x = concat([obs, action]) (critic.py:185-188) -> backbone MLP -> Dense(1): no time rows, the action
   // rows FOLLOW the observation rows, one output
   pl.A = d.x_dim; pl.C = d.cond_dim; pl.T = 1; pl.L = d.n_hidden; pl.D = 0; pl.Dp = 0;
-  pl.AO = 1; pl.x_row0 = pl.C; pl.c_row0 = 0;
+  pl.AO = 1; pl.x_row0 = c->obs_dim; pl.c_row0 = 0;
   pl.H = d.hidden[0];
   plan_layout(d, pl);
   pl.mode = MODE_EVAL;
   return FRL_OK;
 }
 
+static size_t critic_ws_floats(const FrlCriticDesc* desc, const Plan& pl, bool hoist) {
+  const size_t E = (size_t)desc->ensemble, B = (size_t)pl.B;
+  size_t n = E * pl.total_floats + ((E * B + 63) & ~(size_t)63);
+  if (hoist) n += (E * (size_t)desc->n_states * pl.H + 63) & ~(size_t)63;
+  return n;
+}
+
 size_t frl_critic_workspace_bytes(const FrlCriticDesc* desc) {
-  FrlDesc d; Plan pl;
-  if (critic_plan(desc, d, pl) != FRL_OK) return 0;
-  const size_t B = (size_t)pl.B;
-  return ((size_t)desc->ensemble * pl.total_floats + (((size_t)desc->ensemble * B + 63) & ~(size_t)63)) * sizeof(float);
+  FrlDesc d; Plan pl; bool hoist;
+  if (critic_plan(desc, d, pl, hoist) != FRL_OK) return 0;
+  return critic_ws_floats(desc, pl, hoist) * sizeof(float);
 }
 
 int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, const FrlSelectBufs* bufs,
                       void* workspace, size_t workspace_bytes, void* hip_stream) {
-  FrlDesc d; Plan pl;
-  int rc = critic_plan(desc, d, pl);
+  FrlDesc d; Plan pl; bool hoist;
+  int rc = critic_plan(desc, d, pl, hoist);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
-  const size_t need = frl_critic_workspace_bytes(desc);
+  const size_t need = critic_ws_floats(desc, pl, hoist) * sizeof(float);
   if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
   if (workspace_bytes < need) { set_error("workspace %zu B < required %zu B", workspace_bytes, need); return FRL_EWORKSPACE; }
   if (pl.B == 0) return FRL_OK;
@@ -405,9 +414,10 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
   for (int l = 0; l <= desc->n_hidden; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
   hipStream_t stream = (hipStream_t)hip_stream;
-  const int E = desc->ensemble, L = pl.L, H = pl.H, K0 = pl.C + pl.A;
+  const int E = desc->ensemble, L = pl.L, H = pl.H, K0 = desc->obs_dim + pl.A;
   float* ws = (float*)workspace;
   float* qm = ws + (size_t)E * pl.total_floats;                      // (E, B) member scores
+  float* zs = qm + (((size_t)E * pl.B + 63) & ~(size_t)63);          // (E, n_states, H) hoisted Dense_0 slices
   for (int e = 0; e < E; ++e) {
     // member e of every stacked leaf (Ensemblize: nn.vmap with variable_axes params = 0, critic.py:154-172)
     PArgs pa;
@@ -421,9 +431,15 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
     pa.ws = wse; pa.plan = pl; pa.kind = FRL_KIND_CNF; pa.time_embed = FRL_TEMB_NONE;
     rc = launch_prepare(pa, stream);
     if (rc != FRL_OK) return rc;
+    float* zse = zs + (size_t)e * desc->n_states * H;
+    if (hoist) {
+      rc = launch_state_bias(bufs->obs, desc->n_states, desc->obs_dim, H, pa.p.kernel[0], pa.p.bias[0], zse, stream);
+      if (rc != FRL_OK) return rc;
+    }
     KArgs a;
     memset(&a, 0, sizeof(a));
-    a.xT = bufs->actions; a.cond = bufs->obs; a.x0 = qm + (size_t)e * pl.B;
+    a.xT = bufs->actions; a.cond = hoist ? nullptr : bufs->obs; a.x0 = qm + (size_t)e * pl.B;
+    a.state_bias = hoist ? zse : nullptr;
     for (int l = 1; l < L; ++l) { a.wh[l - 1] = pa.p.kernel[l]; a.bh[l - 1] = pa.p.bias[l]; }
     a.ws_coef = wse + pl.off_coef; a.ws_tb = wse + pl.off_tb; a.ws_w0p = wse + pl.off_w0p;
     a.ws_wlp = wse + pl.off_wlp; a.ws_wlq = wse + pl.off_wlq; a.ws_blp = wse + pl.off_blp;

@@ -106,6 +106,61 @@ frl_cond_embed_kernel(int act, const float* __restrict__ obs, long long n_states
   }
 }
 
+// Per-state slice of a Dense layer: zs[state][f] = bias[f] + sum_k obs[state][k] W[k][f], f < H (H a multiple of 128).
+// Used to hoist the observation rows of a critic's Dense_0 out of the per-candidate work (critic.py:185-188 concatenates
+// [obs, action]; the obs part is the same for every candidate of a state): S x H MACs once per STATE.  Same tiling as
+// layer 1 above, one 128-feature group at a time.
+__global__ void __launch_bounds__(256)
+frl_state_bias_kernel(const float* __restrict__ obs, long long n_states, int S, int H, const float* w, const float* b,
+                      float* __restrict__ zs) {
+  const int ROWB = H * 4;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const long long wt = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long state = wt * 32 + li;
+  if (wt * 32 >= n_states) return;
+  const bool valid = state < n_states;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, S * ROWB, 0x00020000);
+  const int nk = (S + 1) / 2;
+  const float* orow = obs + (valid ? state : 0) * S;
+  for (int g = 0; g < H / 128; ++g) {
+    f32x16 acc[4];
+    cfor<16>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      const f32x4 bv = *(const f32x4*)(b + 128 * g + 4 * (CE_ROWR(r) + 4 * lh));
+      cfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; acc[j][r] = bv[j]; });
+    });
+#pragma unroll 4
+    for (int s = 0; s < nk; ++s) {
+      const int k = 2 * s + lh;
+      const float bop = (valid && k < S) ? orow[k] : 0.0f;
+      // lane (li, lh): W[k = 2 s + lh][128 g + 4 li .. + 3]; rows beyond S read as zero (descriptor bounds)
+      const f32x4 aw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lh * ROWB + 512 * g + li * 16, s * 2 * ROWB, 0));
+      cfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[j], bop, acc[j], 0, 0, 0); });
+    }
+    if (valid) {
+      float* zrow = zs + state * H + 128 * g;
+      cfor<16>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        f32x4 v;
+        cfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; v[j] = acc[j][r]; });
+        *(f32x4*)(zrow + 4 * (CE_ROWR(r) + 4 * lh)) = v;
+      });
+    }
+  }
+}
+
+int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, const float* w, const float* b, float* zs,
+                      hipStream_t stream) {
+  if (n_states <= 0) return FRL_OK;
+  if (H % 128 != 0) { set_error("state bias: width %d is not a multiple of 128", H); return FRL_EUNSUPPORTED; }
+  const long long n_wt = (n_states + 31) / 32;
+  const int grid = (int)((n_wt + 3) / 4);
+  hipLaunchKernelGGL(frl_state_bias_kernel, dim3(grid), dim3(256), 0, stream, obs, n_states, in_dim, H, w, b, zs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("state bias launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
 int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim, const float* w0, const float* b0,
                       const float* w1, const float* b1, float* cfeat, hipStream_t stream) {
   if (n_states <= 0) return FRL_OK;

@@ -133,6 +133,7 @@ struct KArgs {
   int particles, A, C, T, L, H, TR, mode, clip;
   int NE;                                 // network evaluations per chain (table rows); = T except dpm2
   int AO;                                 // network outputs per chain (= A except MODE_EVAL)
+  const float* state_bias;                // MODE_EVAL: [n_states][H] Dense_0 accumulator init per STATE (hoisted obs rows) or NULL
   int w0p_bytes;
   float x_min, x_max;
   int XR, AR, CK, merged, n_l0, NS, ntiles;
@@ -259,6 +260,8 @@ int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);  
 size_t bf16_lds_bytes(int T, int L);
 int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim, const float* w0, const float* b0,
                        const float* w1, const float* b1, float* cfeat, hipStream_t stream);
+int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, const float* w, const float* b, float* zs,
+                      hipStream_t stream);
 int launch_critic_select(const float* q_members, int E, long long n_states, int particles, int A, const float* actions,
                          const float* gumbel, float inv_temperature, float* q, int32_t* best_idx, float* best_action,
                          hipStream_t stream);

@@ -147,7 +147,21 @@ frl_sampler_rs_kernel(const KArgs a) {
 
     for (int j = 0; j < a.NE; ++j) {   // one iteration per network evaluation (= per sampler step, except dpm2: two)
       // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
-      bias_init(P, s_tb + j * H);
+      if (a.state_bias != nullptr) {
+        // hoisted per-state slice of Dense_0 (critic: bias + obs rows, computed once per state): every lane fetches the
+        // accumulator inits of ITS state; candidates of one state share the cache lines
+        const float* zrow = a.state_bias + (valid ? state : 0) * H;
+        sfor<NG>([&](auto GI) {
+          constexpr int g = decltype(GI)::value;
+          sfor<NR>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            const f32x4 bv = *(const f32x4*)(zrow + g * GW + 4 * (G::rowr(r) + 4 * ls));
+            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] = bv[jj]; });
+          });
+        });
+      } else {
+        bias_init(P, s_tb + j * H);
+      }
       sfor<N0>([&](auto NI) {
         constexpr int n = decltype(NI)::value;
         if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});

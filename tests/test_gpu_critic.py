@@ -51,7 +51,10 @@ def _run(B, N, S, A, hidden, act, E, temperature, seed):
     dict(B=5, N=1, S=11, A=3, hidden=(256,), act="silu", E=1, temperature=0.0, seed=4),
     dict(B=9, N=130, S=0, A=4, hidden=(256, 256), act="mish", E=3, temperature=0.0, seed=5),            # > 64 candidates, no obs
     dict(B=12, N=16, S=39, A=8, hidden=(512, 512), act="gelu_tanh", E=2, temperature=0.0, seed=6),      # 512-wide geometry
-], ids=lambda c: f"B{c['B']}xN{c['N']}-{c['act']}-E{c['E']}")
+    dict(B=40, N=64, S=376, A=17, hidden=(256, 256), act="relu", E=2, temperature=0.0, seed=7),         # cfg4: QVPO humanoid critic
+    dict(B=33, N=1, S=100, A=6, hidden=(256, 256), act="mish", E=2, temperature=0.0, seed=8),           # wide obs, one candidate
+    dict(B=33, N=1, S=20, A=6, hidden=(256, 256), act="mish", E=2, temperature=0.0, seed=9),            # direct path (no hoist)
+], ids=lambda c: f"B{c['B']}xN{c['N']}-S{c['S']}-{c['act']}-E{c['E']}")
 def test_critic_select(cfg):
     _run(**cfg)
 
@@ -81,7 +84,7 @@ def test_sample_and_select_end_to_end():
 def test_critic_unsupported_is_loud():
     import torch
     import flowrl_hip as fh
-    critic = fh.Ensemblize(base=fh.ScalarCritic(backbone=fh.MLP(hidden_dims=[256, 256], activation="relu")), ensemble_size=2)
-    p = fh.init_critic_params(critic, 376, 17, device="cuda")       # humanoid observation: beyond the 128 condition rows
+    critic = fh.Ensemblize(base=fh.ScalarCritic(backbone=fh.MLP(hidden_dims=[384, 384], activation="relu")), ensemble_size=2)
+    p = fh.init_critic_params(critic, 11, 3, device="cuda")         # hidden width without a kernel
     with pytest.raises(fh.FlowRLHipUnsupported):
-        fh.critic_select(critic, p, torch.zeros((4, 376), device="cuda"), torch.zeros((4, 2, 17), device="cuda"), 2)
+        fh.critic_select(critic, p, torch.zeros((4, 11), device="cuda"), torch.zeros((4, 2, 3), device="cuda"), 2)
