@@ -69,12 +69,13 @@ static int validate_desc(const FrlDesc* d) {
   {
     Plan pl;
     plan_from_desc(*d, pl);
+    // (a condition wider than the budget is hoisted per state, Plan.hoist: CK = 0 then)
     const bool ok = (pl.TR == 32) ? ((pl.AR <= 4 && pl.CK <= 12) || (pl.AR <= 12 && pl.CK <= 64)) : (pl.AR <= 4 && pl.CK <= 12);
     if (!ok) {
-      set_error("x_dim %d / cond_dim %d exceed the compiled operand budgets for hidden width %d "
-                "(256: x_dim <= 24, cond_dim <= 128; 512: x_dim <= 16, cond_dim <= 48)", d->x_dim, d->cond_dim, pl.H);
+      set_error("x_dim %d exceeds the compiled operand budget for hidden width %d (256: x_dim <= 24; 512: x_dim <= 16)", d->x_dim, pl.H);
       return FRL_EUNSUPPORTED;
     }
+    if (pl.hoist && pl.H % 128 != 0) { set_error("hidden width %d: per-state hoist needs a multiple of 128", pl.H); return FRL_EUNSUPPORTED; }
   }
   return FRL_OK;
 }
@@ -122,9 +123,18 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
     em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
     if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_cks) - (pl.XR + 2 * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
-    *executed = 2.0 * B * T * em + cond_flops;
+    *executed = 2.0 * B * T * em + cond_flops + (pl.hoist ? 2.0 * (double)desc->n_states * pl.C * pl.H : 0.0);   // hoisted cond rows: once per state
   }
   return 2.0 * B * T * macs + cond_flops;
+}
+
+double frl_hoisted_flops(const FrlDesc* desc) {
+  if (validate_desc(desc) != FRL_OK) return 0.0;
+  Plan pl;
+  plan_from_desc(*desc, pl);
+  if (!pl.hoist) return 0.0;
+  const double evals = (desc->solver == FRL_SOLVER_DPM2 ? 2.0 : 1.0) * desc->steps * (double)pl.B;
+  return 2.0 * (evals - (double)desc->n_states) * pl.C * pl.H;
 }
 
 int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
@@ -199,6 +209,14 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
     if (rc != FRL_OK) return rc;
     a.cond = cfeat;
   }
+  if (pl.hoist) {
+    // cond rows of Dense_0, once per state: zs[state] = cond[state] @ kernel_0[A + D' :]  (the bias lives in tb)
+    float* zs = (float*)workspace + pl.off_zs;
+    rc = launch_state_bias(a.cond, desc->n_states, pl.C, pl.H, params->kernel[0] + (size_t)pl.c_row0 * pl.H, nullptr, zs,
+                           (hipStream_t)hip_stream);
+    if (rc != FRL_OK) return rc;
+    a.state_bias = zs;
+  }
   a.x0 = bufs->x0;
   a.xt_hist = desc->want_history ? bufs->xt_hist : nullptr;
   a.eps_hist = desc->want_history ? bufs->eps_hist : nullptr;
@@ -207,6 +225,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.NE = pl.NE; a.AO = pl.AO;
+  if (pl.hoist) a.C = 0;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
   a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
@@ -217,7 +236,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   }
   // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)
   static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
-  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER)
+  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER && !pl.hoist)
     return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
   switch (desc->act) {
     case FRL_ACT_MISH: return launch_sampler_rs_act<FRL_ACT_MISH>(a, (hipStream_t)hip_stream);
@@ -433,7 +452,7 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
     if (rc != FRL_OK) return rc;
     float* zse = zs + (size_t)e * desc->n_states * H;
     if (hoist) {
-      rc = launch_state_bias(bufs->obs, desc->n_states, desc->obs_dim, H, pa.p.kernel[0], pa.p.bias[0], zse, stream);
+      rc = launch_state_bias(bufs->obs, desc->n_states, desc->obs_dim, H, pa.p.kernel[0], nullptr, zse, stream);   // bias_0 is in tb
       if (rc != FRL_OK) return rc;
     }
     KArgs a;

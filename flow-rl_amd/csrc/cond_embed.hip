@@ -106,7 +106,7 @@ frl_cond_embed_kernel(int act, const float* __restrict__ obs, long long n_states
   }
 }
 
-// Per-state slice of a Dense layer: zs[state][f] = bias[f] + sum_k obs[state][k] W[k][f], f < H (H a multiple of 128).
+// Per-state slice of a Dense layer: zs[state][f] = (bias[f] or 0) + sum_k obs[state][k] W[k][f], f < H (H a multiple of 128).
 // Used to hoist the observation rows of a critic's Dense_0 out of the per-candidate work (critic.py:185-188 concatenates
 // [obs, action]; the obs part is the same for every candidate of a state): S x H MACs once per STATE.  Same tiling as
 // layer 1 above, one 128-feature group at a time.
@@ -126,7 +126,7 @@ frl_state_bias_kernel(const float* __restrict__ obs, long long n_states, int S, 
     f32x16 acc[4];
     cfor<16>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
-      const f32x4 bv = *(const f32x4*)(b + 128 * g + 4 * (CE_ROWR(r) + 4 * lh));
+      const f32x4 bv = (b != nullptr) ? *(const f32x4*)(b + 128 * g + 4 * (CE_ROWR(r) + 4 * lh)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       cfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; acc[j][r] = bv[j]; });
     });
 #pragma unroll 4

@@ -52,7 +52,9 @@ struct Plan {
   int TR, KS, NR;       // geometry: MFMA tile rows (32: 32x32x2, 16: 16x16x4), k per MFMA, accumulators per block
   int XR;               // layer-0 x rows in the packed image: 4 KS ceil(A / 4KS) (row a = ROWR(r) + 4 s)
   int AR;               // x registers per lane = XR / KS
-  int CK;               // layer-0 cond k-steps = ceil(C / KS)
+  int CK;               // layer-0 cond k-steps = ceil(C / KS); 0 when the cond rows are hoisted
+  int hoist;            // 1: the cond rows of Dense_0 are contracted once per STATE (frl_state_bias_kernel) and enter the
+                        //    sampler as a per-state accumulator init: many chains per state, or a cond wider than the budget
   int K0p;              // rows of the packed layer-0 image = XR + KS*CK
   int merged;           // (LDS-slab kernel only) 1: x rows and cond rows share ONE slab (K0p <= 32)
   int n_l0;             // (LDS-slab kernel only) layer-0 slabs
@@ -60,7 +62,7 @@ struct Plan {
   int mode;
   long long B;
   // workspace layout (float offsets)
-  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, total_floats;
+  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, off_zs, total_floats;
   size_t w0p_rows;
   // bf16 MFMA variant (32x32x16, hidden width 256): weight stream image = bf_ns chunks of 32 KB per step
   int bf16;             // 1: desc.dtype == FRL_DTYPE_BF16
@@ -90,6 +92,8 @@ inline int plan_layout(const FrlDesc& d, Plan& p) {
   p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
   p.AR = p.XR / p.KS;
   p.CK = (p.C + p.KS - 1) / p.KS;
+  p.hoist = (d.dtype == FRL_DTYPE_F32 && p.C > 0 && ((d.particles >= 4 && p.C >= 32) || p.CK > (p.TR == 32 ? 64 : 12))) ? 1 : 0;
+  if (p.hoist) p.CK = 0;
   p.K0p = p.XR + p.KS * p.CK;
   p.merged = (p.K0p <= SLAB_ROWS) ? 1 : 0;
   p.n_l0 = p.merged ? 1 : 1 + (p.KS * p.CK + SLAB_ROWS - 1) / SLAB_ROWS;
@@ -112,6 +116,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p) {
   p.off_wlq = take((size_t)p.H * 64);         // per-lane packed image: H/TR * NR/4 loads x 64 lanes x 4 floats
   p.off_blp = take(LAST_PAD);
   p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
+  p.off_zs = take(p.hoist ? (size_t)d.n_states * p.H : 0);                     // hoisted cond slice of Dense_0, one row per state
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
   p.bf_nxk = (p.A <= 16 && p.C <= 32) ? 1 : 2;   // narrow instantiation <8, 2> or wide <16, 8>
   p.bf_cks = (p.bf_nxk == 1) ? 2 : 8;

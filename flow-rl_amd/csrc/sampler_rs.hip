@@ -36,7 +36,7 @@
 
 namespace frl {
 
-template <int TR, int H, int ACT, int NRX, int CKMAX>
+template <int TR, int H, int ACT, int NRX, int CKMAX, bool EXT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_rs_kernel(const KArgs a) {
   typedef Geo<TR> G;
@@ -142,25 +142,27 @@ frl_sampler_rs_kernel(const KArgs a) {
       cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
     });
 
-    float aux[NRX];     // dpm++2m: previous x0_hat (scan carry, continuous_ddpm.py:219); dpm2: the step's original xt
-    sfor<NRX>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
+    // EXT only — dpm++2m: previous x0_hat (scan carry, continuous_ddpm.py:219); dpm2: the step's original xt
+    float aux[EXT ? NRX : 1];
+    sfor<(EXT ? NRX : 1)>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
 
     for (int j = 0; j < a.NE; ++j) {   // one iteration per network evaluation (= per sampler step, except dpm2: two)
       // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
-      if (a.state_bias != nullptr) {
-        // hoisted per-state slice of Dense_0 (critic: bias + obs rows, computed once per state): every lane fetches the
-        // accumulator inits of ITS state; candidates of one state share the cache lines
-        const float* zrow = a.state_bias + (valid ? state : 0) * H;
-        sfor<NG>([&](auto GI) {
-          constexpr int g = decltype(GI)::value;
-          sfor<NR>([&](auto RI) {
-            constexpr int r = decltype(RI)::value;
-            const f32x4 bv = *(const f32x4*)(zrow + g * GW + 4 * (G::rowr(r) + 4 * ls));
-            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] = bv[jj]; });
+      bias_init(P, s_tb + j * H);
+      if constexpr (EXT) {
+        if (a.state_bias != nullptr) {
+          // hoisted per-state slice of Dense_0 (the condition / observation rows, computed once per state by
+          // frl_state_bias_kernel): every lane adds the row of ITS state; chains of one state share the cache lines
+          const float* zrow = a.state_bias + (valid ? state : 0) * H;
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            sfor<NR>([&](auto RI) {
+              constexpr int r = decltype(RI)::value;
+              const f32x4 bv = *(const f32x4*)(zrow + g * GW + 4 * (G::rowr(r) + 4 * ls));
+              sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] += bv[jj]; });
+            });
           });
-        });
-      } else {
-        bias_init(P, s_tb + j * H);
+        }
       }
       sfor<N0>([&](auto NI) {
         constexpr int n = decltype(NI)::value;
@@ -252,7 +254,7 @@ frl_sampler_rs_kernel(const KArgs a) {
         const int ai = G::rowr(r) + 4 * ls;
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
-        const float c6 = s_coef[j * COEF_STRIDE + 6];             // dpm2: 1 on the second evaluation of a step
+        const float c6 = EXT ? s_coef[j * COEF_STRIDE + 6] : 0.0f;   // dpm2: 1 on the second evaluation of a step
         if (a.xt_hist != nullptr && in && c6 == 0.0f) {           // history = (xt, eps_theta) of the step, :217
           const int jh = (a.mode == MODE_CDDPM_DPM2) ? j >> 1 : j;
           const long long o = ((long long)jh * a.B + chain) * a.A + ai;
@@ -277,25 +279,25 @@ frl_sampler_rs_kernel(const KArgs a) {
           float x0h = (xt - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * x0h + c3 * eps;                                 // :177
-        } else if (a.mode == MODE_CDDPM_DPMPP2M) {
+        } else if (EXT && a.mode == MODE_CDDPM_DPMPP2M) {
           float x0h = (xt - c1 * eps) / c0;                         // :165
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
-          const float d = c4 * x0h - c5 * aux[r];                   // :207-211 (c4 = 1, c5 = 0 on the first-order step)
+          const float d = c4 * x0h - c5 * aux[EXT ? r : 0];         // :207-211 (c4 = 1, c5 = 0 on the first-order step)
           xn = c2 * xt - c3 * d;                                    // :212
-          aux[r] = x0h;                                             // carry, :217
-        } else if (a.mode == MODE_EVAL) {
+          aux[EXT ? r : 0] = x0h;                                   // carry, :217
+        } else if (EXT && a.mode == MODE_EVAL) {
           xn = eps;                                                 // plain evaluation: the outputs themselves
-        } else if (a.mode == MODE_CDDPM_DPM2) {
-          const float xo = (c6 == 0.0f) ? xt : aux[r];              // both x0_hats come from the ORIGINAL xt, :165,:194
+        } else if (EXT && a.mode == MODE_CDDPM_DPM2) {
+          const float xo = (c6 == 0.0f) ? xt : aux[EXT ? r : 0];    // both x0_hats come from the ORIGINAL xt, :165,:194
           float x0h = (xo - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * x0h + c3 * eps;                                 // :187 (to the midpoint) / :196 (full step)
-          aux[r] = xo;
+          aux[EXT ? r : 0] = xo;
         } else {
           xn = xt + eps / c0;                                       // cnf.py:108
           if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
         }
-        xs[r] = (a.mode == MODE_EVAL) ? ((valid && ai < a.AO) ? xn : 0.0f) : (in ? xn : 0.0f);
+        xs[r] = (EXT && a.mode == MODE_EVAL) ? ((valid && ai < a.AO) ? xn : 0.0f) : (in ? xn : 0.0f);
       });
     }
 
@@ -321,9 +323,9 @@ static int device_cus_rs() {
   return cus[dev];
 }
 
-template <int TR, int H, int ACT, int NRX, int CKMAX>
-static int launch_inst(const KArgs& a, hipStream_t stream) {
-  auto kern = frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX>;
+template <int TR, int H, int ACT, int NRX, int CKMAX, bool EXT>
+static int launch_inst_v(const KArgs& a, hipStream_t stream) {
+  auto kern = frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX, EXT>;
   const int ncu = device_cus_rs();
   const long long n_wt = (a.B + TR - 1) / TR;
   long long per_cu = (n_wt + ncu - 1) / ncu;
@@ -345,6 +347,15 @@ static int launch_inst(const KArgs& a, hipStream_t stream) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
+}
+
+// Two builds of every geometry: the plain one (ddpm / ddim / Euler, condition contracted in the kernel) keeps the
+// register budget of the tuned hot loop; EXT adds what the rarer paths need (dpm2 / dpm++2m carry registers, plain
+// evaluation for critics, per-state hoisted condition rows).
+template <int TR, int H, int ACT, int NRX, int CKMAX>
+static int launch_inst(const KArgs& a, hipStream_t stream) {
+  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, true>(a, stream);
+  return launch_inst_v<TR, H, ACT, NRX, CKMAX, false>(a, stream);
 }
 
 template <int ACT>

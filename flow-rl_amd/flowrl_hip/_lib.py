@@ -91,6 +91,7 @@ EXPORTS = {
     "frl_validate": (C.c_int, [C.POINTER(FrlDesc)]),
     "frl_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
     "frl_algorithmic_flops": (C.c_double, [C.POINTER(FrlDesc), C.POINTER(C.c_double)]),
+    "frl_hoisted_flops": (C.c_double, [C.POINTER(FrlDesc)]),
     "frl_sampler_prepare": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule),
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_sampler_run": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlFwdBufs),

@@ -239,6 +239,11 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
  * really issues (time slice hoisted, edge layers zero-padded). */
 double frl_algorithmic_flops(const FrlDesc* desc, double* executed);
 
+/* FLOPs of the algorithmic count above that this build does NOT execute per chain because the condition rows of
+ * Dense_0 are contracted once per state instead (many chains per state, or a condition beyond the operand budget):
+ * 2 * (B * evaluations - n_states) * C * H, else 0.  SURVEY.md 8(d): subtract it when quoting a fraction of peak. */
+double frl_hoisted_flops(const FrlDesc* desc);
+
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* frl_last_error(void);
 

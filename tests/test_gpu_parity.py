@@ -152,6 +152,17 @@ def test_cddpm_humanoid_wide_operands():
                   schedule="cosine", seed=24))
 
 
+def test_cond_rows_hoisted_per_state():
+    # many chains per state and a wide condition: the cond rows of Dense_0 are contracted once per state
+    # (frl_state_bias_kernel) — which also admits a condition beyond the 128-row operand budget (raw humanoid obs)
+    _check(H.Case("hoist-raw-obs-376", "cddpm", A=17, S=376, T=6, B=6 * 16, particles=16, temb="learnable_fourier",
+                  schedule="cosine", seed=40))
+    _check(H.Case("hoist-wide-single", "ddpm", A=3, S=200, T=4, B=70, seed=41))           # particles = 1, over budget
+    _check(H.Case("hoist-512", "cnf", A=8, S=39, T=5, B=8 * 12, particles=12, hidden=(512, 512), act="gelu_tanh", temb=None,
+                  clip=False, seed=42))
+    _check(H.Case("hoist-ragged-particles", "ddpm", A=3, S=40, T=5, B=9 * 50, particles=50, seed=43))
+
+
 def test_cddpm_dacer_cond_embedding():
     # cfg4: DACER / QVPO humanoid shape (obs 376 -> cond_embedding 128 -> 128, act 17, 256x3 mish, T=20, cosine,
     # learnable-Fourier time embedding, clip +-1), particles per state broadcast in-kernel
