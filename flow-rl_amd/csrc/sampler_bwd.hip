@@ -449,135 +449,164 @@ __device__ __forceinline__ int stash_feature(int row2, int e, int lane) {
   return 128 * (blk >> 2) + (blk & 3) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
 }
 
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-frl_bwd_dw_kernel(const BArgs b) {
-  constexpr int H = 256, LDP = 33;
+// Pipeline: the stash blocks of tile-step u + 1 are fetched into registers while tile-step u is contracted, staged into the
+// other half of a double-buffered LDS tile pair, one barrier per tile-step.  A workgroup owns a contiguous STEP-MAJOR range
+// of tile-steps (u = j * n_wt + wt), so the per-step column sums that make dL/dtb stay in a register between flushes.
+template <int KIND>   // 0: Dense_0 (X = [x_j ; cond], one 32-row block)  1: hidden  2: Dense_L (G = dL/deps, one block)
+__device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* smem, long long u0, long long u1, long long n_wt) {
+  constexpr int H = 256, LDP = 33, TILE = H * LDP;
   const KArgs& a = b.k;
-  extern __shared__ __attribute__((aligned(16))) float smem_dw[];
-  float* sX = smem_dw;
-  float* sG = smem_dw + H * LDP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;       // 8 waves: 4 (X blocks 2 wm, 2 wm + 1) x 2 (G blocks 4 wn .. 4 wn + 3)
   const int A = a.A, C = a.C, T = a.T, L = a.L;
-  const long long n_ts = b.n_ts;
+  constexpr int NM = (KIND == 1) ? 2 : 1, NN = (KIND == 1) ? 4 : 1;
+  const int mb0 = (KIND == 1) ? 2 * wm : (KIND == 2 ? wave : 0);
+  const int nb0 = (KIND == 1) ? 4 * wn : (KIND == 0 ? wave : 0);
 
-  for (int lam = 0; lam <= L; ++lam) {
-    // operand shapes of this layer: X rows (in-features) / G rows (out-features), in 32-row blocks
-    const int xb = (lam == 0) ? 1 : 8, gb = (lam == L) ? 1 : 8;
-    f32x16 acc[2][4];
-    sfor<2>([&](auto MI) { sfor<4>([&](auto NI) { sfor<16>([&](auto RI) {
-      acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
-    float bsum = 0.0f;                                   // column sum of G for feature `tid` (bias gradient)
+  f32x16 acc[NM][NN];
+  sfor<NM>([&](auto MI) { sfor<NN>([&](auto NI) { sfor<16>([&](auto RI) {
+    acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
+  float bsum = 0.0f;                                   // column sum of G for feature `tid` (bias gradient)
+  int jcur = -1;
 
-    for (long long ts = blockIdx.x; ts < n_ts; ts += gridDim.x) {
-      const long long wt = ts / T;
-      const int j = (int)(ts - wt * T);
-      const size_t srow = (size_t)ts * L * 8192;
-      __syncthreads();                                   // previous tile-step's readers are done with the LDS tiles
-      // ---- stage X ----
-      if (lam == 0) {
-        // rows [0, A): x_j ; [A, A+C): cond ; rest zero.  One chain per (row, lane&31)
-        for (int idx = tid; idx < 32 * 32; idx += 512) {
-          const int row = idx >> 5, c = idx & 31;
-          const long long chain = wt * 32 + c;
-          float v = 0.0f;
-          if (chain < a.B) {
-            if (row < A) v = b.xt_hist[((long long)j * a.B + chain) * A + row];
-            else if (row < A + C) v = a.cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
-          }
-          sX[row * LDP + c] = v;
-        }
-      } else {
-        const float* src = b.hd + srow + (size_t)(lam - 1) * 8192;
-        for (int row2 = wave; row2 < 64; row2 += 8) {
-          const f32x2 v = *(const f32x2*)(src + ((size_t)row2 * 64 + lane) * 2);
-          sX[stash_feature(row2, 0, lane) * LDP + li] = v[0];
-          sX[stash_feature(row2, 1, lane) * LDP + li] = v[1];
-        }
-      }
-      // ---- stage G ----
-      if (lam == L) {
-        // dL/deps: [4 regs][64 lanes], action row = ROWR(r) + 4 s
-        for (int idx = tid; idx < 32 * 32; idx += 512) sG[(idx >> 5) * LDP + (idx & 31)] = 0.0f;
-        __syncthreads();
-        if (wave < 4) {
-          const int r = wave;                            // 4 registers <-> waves 0..3
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          sG[row * LDP + li] = b.ge[(size_t)ts * 256 + r * 64 + lane];
-        }
-      } else {
-        const float* src = b.gd + srow + (size_t)lam * 8192;
-        for (int row2 = wave; row2 < 64; row2 += 8) {
-          const f32x2 v = *(const f32x2*)(src + ((size_t)row2 * 64 + lane) * 2);
-          sG[stash_feature(row2, 0, lane) * LDP + li] = v[0];
-          sG[stash_feature(row2, 1, lane) * LDP + li] = v[1];
-        }
-      }
-      __syncthreads();
-      // ---- bias gradient: column sums of G (per-step table for Dense_0: the time branch needs dL/dtb[j]) ----
-      if (tid < gb * 32) {
-        float s = 0.0f;
-#pragma unroll 8
-        for (int c = 0; c < 32; ++c) s += sG[tid * LDP + c];
-        if (lam == 0) atomicAdd(&b.grad_tb[j * H + tid], s);
-        else bsum += s;
-      }
-      // ---- contract over the 32 chains ----
-      // wave (wm, wn): X blocks mb = 4 wm + m (or just block 0), G blocks nb = 4 wn + n; skip blocks that do not exist
-#pragma unroll 4
-      for (int kk = 0; kk < 16; ++kk) {
-        float av[2], bv[4];
-        sfor<2>([&](auto MI) {
-          constexpr int m = decltype(MI)::value;
-          const int mb = (xb == 1) ? 0 : 2 * wm + m;
-          av[m] = sX[(32 * mb + li) * LDP + 2 * kk + lh];
-        });
-        sfor<4>([&](auto NI) {
-          constexpr int n = decltype(NI)::value;
-          const int nb = (gb == 1) ? 0 : 4 * wn + n;
-          bv[n] = sG[(32 * nb + li) * LDP + 2 * kk + lh];
-        });
-        sfor<2>([&](auto MI) {
-          constexpr int m = decltype(MI)::value;
-          if (xb == 8 || (m == 0 && wm == 0)) {
-            sfor<4>([&](auto NI) {
-              constexpr int n = decltype(NI)::value;
-              if (gb == 8 || (n == 0 && wn == 0))
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-            });
-          }
-        });
-      }
-    }
-
-    // ---- flush: dW_l[in][out] += acc (float atomics, two 128-B row segments per instruction) ----
-    float* gk = b.grad_kernel[lam];
-    const int ncol = (lam == L) ? A : H;                  // row length of this layer's kernel
-    sfor<2>([&](auto MI) {
-      constexpr int m = decltype(MI)::value;
-      if (xb == 8 || (m == 0 && wm == 0)) {
-        sfor<4>([&](auto NI) {
-          constexpr int n = decltype(NI)::value;
-          if (gb == 8 || (n == 0 && wn == 0)) {
-            const int mb = (xb == 1) ? 0 : 2 * wm + m, nb = (gb == 1) ? 0 : 4 * wn + n;
-            sfor<16>([&](auto RI) {
-              constexpr int r = decltype(RI)::value;
-              int in = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              const int out = 32 * nb + li;
-              bool ok = out < ncol;
-              if (lam == 0) {                              // staged rows: x | cond  ->  kernel rows x | (time) | cond
-                ok = ok && in < A + C;
-                if (in >= A) in += b.Dp;
-              }
-              if (ok) atomicAdd(&gk[(size_t)in * ncol + out], acc[m][n][r]);
-            });
-          }
-        });
-      }
-    });
-    if (lam > 0 && tid < gb * 32 && tid < ncol) atomicAdd(&b.grad_bias[lam][tid], bsum);
+  if (KIND == 2) {     // dL/deps fills rows 0..7 (+4 s) of its block: the other rows stay zero in both buffers
+    for (int idx = tid; idx < 2 * 32 * LDP; idx += 512) smem[(idx / (32 * LDP)) * 2 * TILE + TILE + idx % (32 * LDP)] = 0.0f;
+    __syncthreads();
   }
+
+  f32x2 xr[8], gr[8];       // staging registers: 64 pair rows / 8 waves
+  float xv[2], gv = 0.0f;
+  auto fetch = [&](long long u) {
+    const int j = (int)(u / n_wt);
+    const long long wt = u - (long long)j * n_wt, ts = wt * T + j;
+    const size_t srow = (size_t)ts * L * 8192;
+    if constexpr (KIND == 0) {
+      sfor<2>([&](auto EI) {
+        constexpr int k = decltype(EI)::value;
+        const int idx = tid + 512 * k, row = idx >> 5, c = idx & 31;
+        const long long chain = wt * 32 + c;
+        float v = 0.0f;
+        if (chain < a.B) {
+          if (row < A) v = b.xt_hist[((long long)j * a.B + chain) * A + row];
+          else if (row < A + C) v = a.cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
+        }
+        xv[k] = v;
+      });
+    } else {
+      const float* src = b.hd + srow + (size_t)(lam - 1) * 8192;
+      sfor<8>([&](auto QI) { constexpr int q = decltype(QI)::value; xr[q] = *(const f32x2*)(src + ((size_t)(wave + 8 * q) * 64 + lane) * 2); });
+    }
+    if constexpr (KIND == 2) {
+      if (wave < 4) gv = b.ge[(size_t)ts * 256 + wave * 64 + lane];
+    } else {
+      const float* src = b.gd + srow + (size_t)lam * 8192;
+      sfor<8>([&](auto QI) { constexpr int q = decltype(QI)::value; gr[q] = *(const f32x2*)(src + ((size_t)(wave + 8 * q) * 64 + lane) * 2); });
+    }
+  };
+  auto stage = [&](float* buf) {
+    float* sX = buf;
+    float* sG = buf + TILE;
+    if constexpr (KIND == 0) {
+      sfor<2>([&](auto EI) { constexpr int k = decltype(EI)::value; const int idx = tid + 512 * k; sX[(idx >> 5) * LDP + (idx & 31)] = xv[k]; });
+    } else {
+      sfor<8>([&](auto QI) {
+        constexpr int q = decltype(QI)::value;
+        const int row2 = wave + 8 * q;
+        sX[stash_feature(row2, 0, lane) * LDP + li] = xr[q][0];
+        sX[stash_feature(row2, 1, lane) * LDP + li] = xr[q][1];
+      });
+    }
+    if constexpr (KIND == 2) {
+      if (wave < 4) sG[((wave & 3) + 8 * (wave >> 2) + 4 * lh) * LDP + li] = gv;   // register r = wave: action row ROWR(r) + 4 s
+    } else {
+      sfor<8>([&](auto QI) {
+        constexpr int q = decltype(QI)::value;
+        const int row2 = wave + 8 * q;
+        sG[stash_feature(row2, 0, lane) * LDP + li] = gr[q][0];
+        sG[stash_feature(row2, 1, lane) * LDP + li] = gr[q][1];
+      });
+    }
+  };
+
+  if (u0 < u1) {
+    fetch(u0);
+    stage(smem);
+    if (u0 + 1 < u1) fetch(u0 + 1);
+  }
+  __syncthreads();
+  for (long long u = u0; u < u1; ++u) {
+    const float* sX = smem + (int)((u - u0) & 1) * 2 * TILE;
+    const float* sG = sX + TILE;
+    // ---- bias gradient: column sums of G (per-step table for Dense_0: the time branch needs dL/dtb[j]) ----
+    if (tid < (KIND == 2 ? 32 : 256)) {
+      if constexpr (KIND == 0) {
+        const int j = (int)(u / n_wt);
+        if (j != jcur) {
+          if (jcur >= 0) atomicAdd(&b.grad_tb[jcur * H + tid], bsum);
+          bsum = 0.0f; jcur = j;
+        }
+      }
+      float s = 0.0f;
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) s += sG[tid * LDP + c];
+      bsum += s;
+    }
+    // ---- contract over the 32 chains ----
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[NM], bv[NN];
+      sfor<NM>([&](auto MI) { constexpr int m = decltype(MI)::value; av[m] = sX[(32 * (mb0 + m) + li) * LDP + 2 * kk + lh]; });
+      sfor<NN>([&](auto NI) { constexpr int n = decltype(NI)::value; bv[n] = sG[(32 * (nb0 + n) + li) * LDP + 2 * kk + lh]; });
+      sfor<NM>([&](auto MI) { constexpr int m = decltype(MI)::value; sfor<NN>([&](auto NI) { constexpr int n = decltype(NI)::value;
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0); }); });
+    }
+    // ---- next tile-step into the other buffer ----
+    if (u + 1 < u1) {
+      stage(smem + (int)(((u - u0) & 1) ^ 1) * 2 * TILE);
+      if (u + 2 < u1) fetch(u + 2);
+    }
+    __syncthreads();
+  }
+
+  // ---- flush: dW_l[in][out] += acc (float atomics, two 128-B row segments per instruction) ----
+  float* gk = b.grad_kernel[lam];
+  const int ncol = (KIND == 2) ? A : H;
+  sfor<NM>([&](auto MI) {
+    constexpr int m = decltype(MI)::value;
+    sfor<NN>([&](auto NI) {
+      constexpr int n = decltype(NI)::value;
+      sfor<16>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        int in = 32 * (mb0 + m) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int out = 32 * (nb0 + n) + li;
+        bool ok = out < ncol;
+        if constexpr (KIND == 0) {                          // staged rows: x | cond  ->  kernel rows x | (time) | cond
+          ok = ok && in < A + C;
+          if (in >= A) in += b.Dp;
+        }
+        if (ok) atomicAdd(&gk[(size_t)in * ncol + out], acc[m][n][r]);
+      });
+    });
+  });
+  if constexpr (KIND == 0) {
+    if (tid < 256 && jcur >= 0) atomicAdd(&b.grad_tb[jcur * H + tid], bsum);
+  } else {
+    if (tid < ncol && tid < 256) atomicAdd(&b.grad_bias[lam][tid], bsum);
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+frl_bwd_dw_kernel(const BArgs b) {
+  extern __shared__ __attribute__((aligned(16))) float smem_dw[];
+  const KArgs& a = b.k;
+  const long long n_wt = (a.B + 31) / 32;
+  const long long U = n_wt * a.T;                         // tile-steps, step-major: u = j * n_wt + wt
+  const long long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+  dw_layer_f32<0>(b, 0, smem_dw, u0, u1, n_wt);
+  for (int lam = 1; lam < a.L; ++lam) dw_layer_f32<1>(b, lam, smem_dw, u0, u1, n_wt);
+  dw_layer_f32<2>(b, a.L, smem_dw, u0, u1, n_wt);
 }
 
 // ---- launcher ---------------------------------------------------------------------------------------------------
@@ -615,7 +644,7 @@ int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
   }
   if (rc != FRL_OK) return rc;
   const long long g2 = b.n_ts < ncu ? b.n_ts : ncu;
-  const size_t lds2 = sizeof(float) * 2 * 256 * 33;
+  const size_t lds2 = sizeof(float) * 4 * 256 * 33;     // two (X, G) tile pairs
   hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(frl_bwd_dw_kernel, dim3((int)g2), dim3(512), lds2, stream, b);
