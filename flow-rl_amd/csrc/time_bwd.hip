@@ -20,7 +20,7 @@ __device__ __forceinline__ double mish_grad_d(double x) {
   return t + x * (1.0 - t * t) * sg;
 }
 
-__global__ void __launch_bounds__(256) frl_time_bwd_kernel(const TBArgs a) {
+__global__ void __launch_bounds__(1024) frl_time_bwd_kernel(const TBArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int T = a.T, D = a.D, H = a.H, A = a.A, half = a.D / 2;
   const float* W0 = a.p.kernel[0];
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) frl_time_bwd_kernel(const TBArgs a) {
 }
 
 int launch_time_bwd(const TBArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(frl_time_bwd_kernel, dim3(1), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(frl_time_bwd_kernel, dim3(1), dim3(1024), 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("time-branch bwd launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
