@@ -87,8 +87,8 @@ def sample(model, w, xT, cond, noise):
     p = w["particles"] if w["particles"] > 1 else None
     cd = w.get("dtype", "f32")
     if w["kind"] == "cnf":
-        return model.sample(None, xT, cond, particles=p, compute_dtype=cd)[1]
-    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd)[1]
+        return model.sample(None, xT, cond, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"))[1]
+    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"))[1]
 
 
 def vjp_step(model, w, xT, cond, noise, g):
@@ -129,7 +129,7 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     desc = _sampler.build_desc(model.network, kind=kind, solver=_lib.FRL_SOLVER_EULER if w["kind"] == "cnf" else _lib.FRL_SOLVER_DDPM,
                                steps=w["T"], n_states=w["B"] // w["particles"], particles=w["particles"], x_dim=w["A"],
                                cond_dim=w["S"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False,
-                               compute_dtype=w.get("dtype", "f32"))
+                               compute_dtype=w.get("dtype", "f32"), tile_policy=w.get("tile_policy", "auto"))
     fp = _sampler.build_params(model.network, model.params, dev, keep)
     fs = _lib.FrlSchedule()
     if w["kind"] == "ddpm":
@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (H = 256 workloads)")
+    ap.add_argument("--tile-policy", default="auto", choices=["auto", "throughput", "latency"],
+                    help="f32 forward kernel build (FrlDesc.tile_policy); auto = latency build when ceil(B/32) <= CUs")
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
@@ -263,6 +265,7 @@ def main():
     if args.batch > 0:
         w["B"] = args.batch
     w["dtype"] = args.dtype
+    w["tile_policy"] = args.tile_policy
     if args.act:
         w["act"] = args.act
     if args.layers > 0:
@@ -318,7 +321,9 @@ def main():
     out = None
     if rank == 0:
         k_ms, flops_alg, flops_exec = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
-        kname = "frl_sampler_rs_kernel"
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        lat = args.tile_policy == "latency" or (args.tile_policy == "auto" and (B + 31) // 32 <= ncu)
+        kname = "frl_sampler_lat_kernel" if (lat and args.dtype == "f32") else "frl_sampler_rs_kernel"
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
             b_ms = vjp_only_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))

@@ -18,6 +18,36 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// f32 network kernel dispatch: latency build for small batches, throughput build otherwise
+static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStream_t stream) {
+  const long long ntiles = (a.B + 31) / 32;
+  bool lat = false;
+  if (tile_policy == FRL_TILE_LATENCY) {
+    if (!sampler_lat_supports(a)) { set_error("tile_policy LATENCY: this configuration has no latency build (H %d, x_dim %d, operand cond rows %d, x rows %d, evaluations %d, LDS %zu bytes)", a.H, a.A, a.C, a.XR, a.NE, lat_lds_bytes(a.NE, a.L, a.H, false)); return FRL_EUNSUPPORTED; }
+    lat = true;
+  } else if (tile_policy == FRL_TILE_AUTO) {
+    lat = ntiles <= device_cus() && sampler_lat_supports(a);
+  }
+  if (lat) {
+    switch (act) {
+      case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, stream);
+      case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, stream);
+      case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, stream);
+      case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, stream);
+      case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, stream);
+      default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, stream);
+    }
+  }
+  switch (act) {
+    case FRL_ACT_MISH: return launch_sampler_rs_act<FRL_ACT_MISH>(a, stream);
+    case FRL_ACT_SILU: return launch_sampler_rs_act<FRL_ACT_SILU>(a, stream);
+    case FRL_ACT_RELU: return launch_sampler_rs_act<FRL_ACT_RELU>(a, stream);
+    case FRL_ACT_GELU_TANH: return launch_sampler_rs_act<FRL_ACT_GELU_TANH>(a, stream);
+    case FRL_ACT_TANH: return launch_sampler_rs_act<FRL_ACT_TANH>(a, stream);
+    default: return launch_sampler_rs_act<FRL_ACT_ELU>(a, stream);
+  }
+}
+
 static int validate_desc(const FrlDesc* d) {
   if (d == nullptr) { set_error("desc is NULL"); return FRL_EINVAL; }
   if (d->abi_version != FRL_ABI_VERSION) { set_error("desc.abi_version %d != library %d", d->abi_version, FRL_ABI_VERSION); return FRL_EINVAL; }
@@ -46,6 +76,7 @@ static int validate_desc(const FrlDesc* d) {
   if (d->act < FRL_ACT_MISH || d->act > FRL_ACT_ELU) { set_error("act %d invalid", d->act); return FRL_EINVAL; }
   if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
   if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
+  if (d->tile_policy < FRL_TILE_AUTO || d->tile_policy > FRL_TILE_LATENCY) { set_error("tile_policy %d invalid", d->tile_policy); return FRL_EINVAL; }
   if (d->cond_embed) {
     if (d->cond_dim != COND_EMBED_DIM) { set_error("cond_embed: cond_dim must be %d (MLP(128,128)), got %d", COND_EMBED_DIM, d->cond_dim); return FRL_EUNSUPPORTED; }
     if (d->cond_in_dim < 1) { set_error("cond_embed: cond_in_dim %d invalid", d->cond_in_dim); return FRL_EINVAL; }
@@ -238,14 +269,8 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
   if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER && !pl.hoist)
     return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
-  switch (desc->act) {
-    case FRL_ACT_MISH: return launch_sampler_rs_act<FRL_ACT_MISH>(a, (hipStream_t)hip_stream);
-    case FRL_ACT_SILU: return launch_sampler_rs_act<FRL_ACT_SILU>(a, (hipStream_t)hip_stream);
-    case FRL_ACT_RELU: return launch_sampler_rs_act<FRL_ACT_RELU>(a, (hipStream_t)hip_stream);
-    case FRL_ACT_GELU_TANH: return launch_sampler_rs_act<FRL_ACT_GELU_TANH>(a, (hipStream_t)hip_stream);
-    case FRL_ACT_TANH: return launch_sampler_rs_act<FRL_ACT_TANH>(a, (hipStream_t)hip_stream);
-    default: return launch_sampler_rs_act<FRL_ACT_ELU>(a, (hipStream_t)hip_stream);
-  }
+  a.wl_raw = params->kernel[desc->n_hidden];
+  return launch_f32_network(a, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
 }
 
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
@@ -467,14 +492,8 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
     a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
     a.mode = MODE_EVAL;
     a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
-    switch (desc->act) {
-      case FRL_ACT_MISH: rc = launch_sampler_rs_act<FRL_ACT_MISH>(a, stream); break;
-      case FRL_ACT_SILU: rc = launch_sampler_rs_act<FRL_ACT_SILU>(a, stream); break;
-      case FRL_ACT_RELU: rc = launch_sampler_rs_act<FRL_ACT_RELU>(a, stream); break;
-      case FRL_ACT_GELU_TANH: rc = launch_sampler_rs_act<FRL_ACT_GELU_TANH>(a, stream); break;
-      case FRL_ACT_TANH: rc = launch_sampler_rs_act<FRL_ACT_TANH>(a, stream); break;
-      default: rc = launch_sampler_rs_act<FRL_ACT_ELU>(a, stream); break;
-    }
+    a.wl_raw = pa.p.kernel[L];
+    rc = launch_f32_network(a, desc->act, FRL_TILE_AUTO, stream);
     if (rc != FRL_OK) return rc;
   }
   return launch_critic_select(qm, E, desc->n_states, desc->particles, pl.A, bufs->actions, bufs->gumbel, bufs->inv_temperature,

@@ -138,6 +138,8 @@ struct KArgs {
   int particles, A, C, T, L, H, TR, mode, clip;
   int NE;                                 // network evaluations per chain (table rows); = T except dpm2
   int AO;                                 // network outputs per chain (= A except MODE_EVAL)
+  const float* wl_raw;                    // Dense_L kernel (H, AO) in place (latency kernel)
+  int lat_tb_global;                      // latency kernel: time-bias rows read from the workspace, not staged in LDS
   const float* state_bias;                // MODE_EVAL: [n_states][H] Dense_0 accumulator init per STATE (hoisted obs rows) or NULL
   int w0p_bytes;
   float x_min, x_max;
@@ -260,6 +262,31 @@ void set_error(const char* fmt, ...);
 int launch_prepare(const PArgs& a, hipStream_t stream);
 int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);   // LDS K-slab variant (H = 256 only), A/B reference
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
+template <int ACT> int launch_sampler_lat_act(const KArgs& a, hipStream_t stream); // latency variant (4 waves per tile), one TU per activation
+// CU count of the current device (cached per thread and device)
+inline int device_cus() {
+  static thread_local int cus[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+// LDS of the latency kernel; the [NE][H] time-bias rows are staged only when they fit (else read through L2 per evaluation)
+inline size_t lat_lds_bytes(int NE, int L, int H, bool tb_rows) {
+  return sizeof(float) * ((tb_rows ? (size_t)NE * H : 0) + (size_t)(L - 1) * H + LAST_PAD + (size_t)NE * COEF_STRIDE + 2 * (size_t)H * 32);
+}
+// AR / CK in the units of the latency kernel (32x32x2: two input rows per k-step), whatever geometry the plan chose
+inline bool sampler_lat_supports(const KArgs& a) {
+  const int ar = 4 * ((a.A + 7) / 8), ck = (a.C + 1) / 2;
+  return (a.H == 256 || a.H == 512) && ((ar <= 4 && ck <= 12) || (ar <= 12 && ck <= 64)) && a.XR >= 2 * ar &&
+         lat_lds_bytes(a.NE, a.L, a.H, false) <= 160 * 1024;
+}
 int launch_prepare_bf16(const FrlParams& p, const Plan& pl, float* ws, hipStream_t stream);   // bf16 weight stream image
 int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256)
 size_t bf16_lds_bytes(int T, int L);

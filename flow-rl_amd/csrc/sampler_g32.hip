@@ -395,19 +395,6 @@ static int launch_act(const KArgs& a, int grid, int block, size_t lds, hipStream
   return FRL_EUNSUPPORTED;
 }
 
-static int device_cus() {
-  static thread_local int cus[16] = {0};
-  int dev = 0;
-  hipGetDevice(&dev);
-  if (dev >= 16) dev = 0;
-  if (cus[dev] == 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return cus[dev];
-}
-
 int launch_sampler_g32(const FrlDesc& d, const KArgs& a0, hipStream_t stream) {
   KArgs a = a0;
   const int ncu = device_cus();

@@ -1,0 +1,330 @@
+// Latency build of the fused T-step sampler (exact-f32 MFMA 32x32x2): ONE workgroup of four waves per tile of 32 chains,
+// the OUTPUT FEATURES of every layer split over the four SIMDs of a CU.
+//
+// The throughput kernel (sampler_rs.hip) gives a wave a whole tile: no barrier, no LDS traffic, 84 % of the MFMA peak
+// once there are >= 1024 wave-tiles — but a tile's step is then 2256 serial MFMAs (145k cycles), and a small batch
+// (acting: agent.sample_actions on 1 .. a few thousand observations, examples/toy2d: 4096 chains x T = 20) leaves most
+// SIMDs idle behind that latency.  Here wave w owns features [H/4 w, H/4 (w + 1)) of every layer:
+//
+//   Dense_0 / hidden layers   each wave contracts ALL inputs for ITS H/4 output features (weights: 8- or 16-byte loads of
+//                             its own columns, streamed L2 -> registers through a ring); the activated outputs go to an
+//                             LDS tile in the B-operand order of the next layer ([k-step/4][lane][4]: one ds_read_b128
+//                             per four k-steps), one barrier per layer, two tiles ping-pong
+//   Dense_L                   split-K: a wave's own activated features ARE B operands already (register r of lane half s
+//                             <-> one feature, as in sampler_rs.hip); the four partial 32 x 32 tiles meet in LDS
+//   epilogue                  every wave applies the update to its own copy of the chain state (same code as sampler_rs)
+//
+// A step is then ~1/4 of the serial MFMA chain plus L + 1 barriers.  Same arithmetic per output as the throughput kernel
+// up to the order of the Dense_L partial sums.  Chosen by the launcher when the batch has no more tiles than the GPU
+// has CUs (FrlDesc.tile_policy overrides).
+#include "frl_device.h"
+
+namespace frl {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int NBW> struct WVec;
+template <> struct WVec<2> {
+  typedef f32x2 type;
+  static __device__ __forceinline__ type ld(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+  }
+};
+template <> struct WVec<4> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type ld(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  }
+};
+
+template <int H, int ACT, int NRX, int CKMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+frl_sampler_lat_kernel(const KArgs a) {
+  typedef Geo<32> G;
+  typedef f32x16 acc_t;
+  constexpr int TR = 32, NR = 16;
+  constexpr int NBW = H / 128;      // 32-row output blocks per wave
+  constexpr int FW = H / 4;         // features per wave
+  constexpr int NK = H / 2;         // k-steps per hidden layer
+  constexpr int ROWB = H * 4;
+  constexpr int RW = 16;            // hidden-layer weight ring (k-steps ahead)
+  constexpr int R0 = 4;             // Dense_0 weight ring
+  typedef WVec<NBW> WV;
+  typedef typename WV::type wv_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, ls = lane >> 5;
+
+  float* s_tb = (float*)smem;                         // [NE][H] (absent when a.lat_tb_global)
+  float* s_bh = s_tb + (a.lat_tb_global ? 0 : a.NE * H);   // [L-1][H]
+  float* s_bl = s_bh + (a.L - 1) * H;                 // [32]
+  float* s_coef = s_bl + LAST_PAD;                    // [NE][8]
+  float* s_act = s_coef + a.NE * COEF_STRIDE;         // 2 x [H/8][64][4]: activations in B-operand order
+  // The two s_act buffers alternate per PHASE (a hidden layer's activation exchange, or the Dense_L partial tiles
+  // [4 waves][16][64], which fit one buffer): phase n writes buffer n & 1, barrier, reads it.  The other buffer was
+  // last read in phase n - 1, which every wave left before it passed barrier n: one barrier per phase is enough.
+  if (!a.lat_tb_global)
+    for (int idx = tid; idx < a.NE * H; idx += 256) s_tb[idx] = a.ws_tb[idx];
+  for (int l = 1; l < a.L; ++l) {
+    const float* bp = pick_ptr_rs(a.bh, l - 1);
+    for (int idx = tid; idx < H; idx += 256) s_bh[(l - 1) * H + idx] = bp[idx];
+  }
+  if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
+  for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += 256) s_coef[idx] = a.ws_coef[idx];
+  __syncthreads();
+
+  // column part of every weight address: this wave's features FW w + NBW i + jb, i = li
+  const unsigned voff_col = (unsigned)(FW * wave + NBW * li) * 4;
+  const unsigned voff_h = ls * ROWB + voff_col;         // hidden / cond rows: k-step's row 2 ks + ls
+  const unsigned voff_x = ls * (4 * ROWB) + voff_col;   // Dense_0 x rows: ROWR(n) + 4 ls
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_w0p, 0, a.w0p_bytes, 0x00020000);
+
+  // Dense_L operands stay resident: k-step (jb, r) contracts feature FW w + NBW (ROWR(r) + 4 ls) + jb, lane i = output row
+  float wl[NBW][NR];
+  {
+    const float* WL = a.wl_raw;
+    sfor<NBW>([&](auto JI) {
+      constexpr int jb = decltype(JI)::value;
+      sfor<NR>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int f = FW * wave + NBW * (G::rowr(r) + 4 * ls) + jb;
+        wl[jb][r] = (li < a.AO) ? WL[(size_t)f * a.AO + li] : 0.0f;
+      });
+    });
+  }
+
+  const int ntiles = (int)((a.B + TR - 1) / TR);
+  int phase = 0;   // runs on across steps and tiles
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long chain = (long long)tile * TR + li;
+    const bool valid = chain < a.B;
+    const long long state = (a.particles == 1) ? chain : chain / a.particles;
+
+    float xs[NRX];
+    sfor<NRX>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      const int ai = G::rowr(r) + 4 * ls;
+      xs[r] = (valid && ai < a.A) ? a.xT[chain * a.A + ai] : 0.0f;
+    });
+    float cb[CKMAX];
+    sfor<CKMAX>([&](auto CI) {
+      constexpr int c = decltype(CI)::value;
+      const int k = 2 * c + ls;
+      cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
+    });
+    float aux[NRX];
+    sfor<NRX>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
+
+    for (int j = 0; j < a.NE; ++j) {
+      acc_t acc[NBW];
+      // ---------------- Dense_0 ------------------------------------------------------------------------
+      if (a.lat_tb_global) {
+        const float* trow = a.ws_tb + (size_t)j * H + FW * wave;
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const wv_t bv = *(const wv_t*)(trow + NBW * (G::rowr(r) + 4 * ls));
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb][r] = bv[jb]; });
+        });
+      } else {
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const wv_t bv = *(const wv_t*)(s_tb + j * H + FW * wave + NBW * (G::rowr(r) + 4 * ls));
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb][r] = bv[jb]; });
+        });
+      }
+      if (a.state_bias != nullptr) {
+        const float* zrow = a.state_bias + (valid ? state : 0) * H + FW * wave;
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const wv_t bv = *(const wv_t*)(zrow + NBW * (G::rowr(r) + 4 * ls));
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb][r] += bv[jb]; });
+        });
+      }
+      float zr[NRX];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+      });
+      {
+        constexpr int N0 = NRX + CKMAX;
+        wv_t r0[R0];
+        auto l0load = [&](auto NI) {
+          constexpr int n = decltype(NI)::value;
+          if constexpr (n < NRX) r0[n % R0] = WV::ld(rs0, voff_x, G::rowr(n) * ROWB);
+          else r0[n % R0] = WV::ld(rs0, voff_h, (a.XR + 2 * (n - NRX)) * ROWB);
+        };
+        sfor<R0 - 1>([&](auto NI) { l0load(NI); });
+        sfor<N0>([&](auto NI) {
+          constexpr int n = decltype(NI)::value;
+          if constexpr (n + R0 - 1 < N0) l0load(std::integral_constant<int, n + R0 - 1>{});
+          const bool live = (n < NRX) ? (n < a.AR) : ((n - NRX) < a.CK);
+          if (live) {
+            float bop;
+            if constexpr (n < NRX) bop = xs[n]; else bop = cb[n - NRX];
+            const wv_t aw = r0[n % R0];
+            sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb] = G::mfma(aw[jb], bop, acc[jb]); });
+          }
+        });
+      }
+
+      // ---------------- hidden layers: activations through LDS, one barrier each ------------------------
+      for (int l = 1; l < a.L; ++l) {
+        float* abuf = s_act + (phase++ & 1) * (H * TR);
+        sfor<NBW>([&](auto JI) {
+          constexpr int jb = decltype(JI)::value;
+          sfor<NR>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            // feature f = FW w + NBW row + jb is contracted by k-step f >> 1 on lane half f & 1 (NBW is even)
+            const int ks = (FW / 2) * wave + (NBW / 2) * (G::rowr(r) + 4 * ls) + (jb >> 1);
+            abuf[(((ks >> 2) * 64) + (jb & 1) * 32 + li) * 4 + (ks & 3)] = act_fn<ACT>(acc[jb][r]);
+          });
+        });
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
+        wv_t ring[RW];
+        sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs, voff_h, 2 * k * ROWB); });
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const wv_t bv = *(const wv_t*)(s_bh + (l - 1) * H + FW * wave + NBW * (G::rowr(r) + 4 * ls));
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb][r] = bv[jb]; });
+        });
+        __syncthreads();
+        const f32x4* bsrc = (const f32x4*)abuf + lane;
+        f32x4 bq = bsrc[0], bqn = bq;
+        sfor<NK>([&](auto KI) {
+          constexpr int k = decltype(KI)::value;
+          if constexpr (k + RW - 1 < NK) ring[(k + RW - 1) % RW] = WV::ld(rs, voff_h, 2 * (k + RW - 1) * ROWB);
+          if constexpr ((k & 3) == 0 && k + 4 < NK) bqn = bsrc[(k / 4 + 1) * 64];
+          const wv_t aw = ring[k % RW];
+          const float bop = bq[k & 3];
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb] = G::mfma(aw[jb], bop, acc[jb]); });
+          if constexpr ((k & 3) == 3) bq = bqn;
+        });
+      }
+
+      // ---------------- Dense_L, split-K over the waves ------------------------------------------------------
+      acc_t O;
+      sfor<NR>([&](auto RI) { O[decltype(RI)::value] = 0.0f; });
+      sfor<NBW>([&](auto JI) {
+        constexpr int jb = decltype(JI)::value;
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          O = G::mfma(wl[jb][r], act_fn<ACT>(acc[jb][r]), O);
+        });
+      });
+      {
+        float* part = s_act + (phase++ & 1) * (H * TR);
+        sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; part[(wave * NR + r) * 64 + lane] = O[r]; });
+        __syncthreads();
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          float s = s_bl[G::rowr(r) + 4 * ls];
+          sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; s += part[(w * NR + r) * 64 + lane]; });
+          O[r] = s;
+        });
+      }
+
+      // ---------------- epilogue (as in sampler_rs.hip) -----------------------------------------------------
+      const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
+      const float c2 = s_coef[j * COEF_STRIDE + 2], c3 = s_coef[j * COEF_STRIDE + 3];
+      const float c4 = s_coef[j * COEF_STRIDE + 4], c5 = s_coef[j * COEF_STRIDE + 5];
+      const float c6 = s_coef[j * COEF_STRIDE + 6];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        const bool in = valid && ai < a.A;
+        const float eps = O[r], xt = xs[r];
+        if (a.xt_hist != nullptr && in && c6 == 0.0f && wave == 0) {
+          const int jh = (a.mode == MODE_CDDPM_DPM2) ? j >> 1 : j;
+          const long long o = ((long long)jh * a.B + chain) * a.A + ai;
+          a.xt_hist[o] = xt;
+          a.eps_hist[o] = eps;
+        }
+        float xn;
+        if (a.mode == MODE_DDPM_DDPM) {
+          float x0h = c0 * (xt - c1 * eps);
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * (c3 * x0h + c4 * xt);
+          xn += c5 * zr[r];
+        } else if (a.mode == MODE_DDPM_DDIM) {
+          xn = c0 * (xt - c1 * eps) + c2 * eps;
+          if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+        } else if (a.mode == MODE_CDDPM_DDPM) {
+          float x0h = (xt - c1 * eps) / c0;
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * x0h + c3 * xt;
+          xn += c5 * zr[r];
+        } else if (a.mode == MODE_CDDPM_DDIM) {
+          float x0h = (xt - c1 * eps) / c0;
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * x0h + c3 * eps;
+        } else if (a.mode == MODE_CDDPM_DPMPP2M) {
+          float x0h = (xt - c1 * eps) / c0;
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          const float d = c4 * x0h - c5 * aux[r];
+          xn = c2 * xt - c3 * d;
+          aux[r] = x0h;
+        } else if (a.mode == MODE_EVAL) {
+          xn = eps;
+        } else if (a.mode == MODE_CDDPM_DPM2) {
+          const float xo = (c6 == 0.0f) ? xt : aux[r];
+          float x0h = (xo - c1 * eps) / c0;
+          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+          xn = c2 * x0h + c3 * eps;
+          aux[r] = xo;
+        } else {
+          xn = xt + eps / c0;
+          if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+        }
+        xs[r] = (a.mode == MODE_EVAL) ? ((valid && ai < a.AO) ? xn : 0.0f) : (in ? xn : 0.0f);
+      });
+    }
+
+    if (wave == 0) {
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        if (valid && ai < a.AO) a.x0[chain * a.AO + ai] = xs[r];
+      });
+    }
+  }
+}
+
+template <int H, int ACT, int NRX, int CKMAX>
+static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
+  auto kern = frl_sampler_lat_kernel<H, ACT, NRX, CKMAX>;
+  const long long ntiles = (a.B + 31) / 32;
+  const int grid = (int)(ntiles < 4LL * ncu ? ntiles : 4LL * ncu);
+  a.lat_tb_global = lat_lds_bytes(a.NE, a.L, H, true) > 160 * 1024 ? 1 : 0;
+  const size_t lds = lat_lds_bytes(a.NE, a.L, H, !a.lat_tb_global);
+  if (lds > 160 * 1024) { set_error("latency sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("latency sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+template <int ACT>
+int launch_sampler_lat_act(const KArgs& a0, hipStream_t stream) {
+  KArgs a = a0;
+  a.AR = 4 * ((a.A + 7) / 8);
+  a.CK = (a.C + 1) / 2;
+  const int ncu = device_cus();
+  const bool narrow = a.AR <= 4 && a.CK <= 12;
+  if (a.H == 256) return narrow ? launch_lat_inst<256, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<256, ACT, 12, 64>(a, ncu, stream);
+  if (a.H == 512) return narrow ? launch_lat_inst<512, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<512, ACT, 12, 64>(a, ncu, stream);
+  set_error("latency sampler: hidden width %d has no kernel", a.H);
+  return FRL_EUNSUPPORTED;
+}
+
+#ifndef FRL_RS_ACT
+#error "compile with -DFRL_RS_ACT=<FRL_ACT_*>: one translation unit per activation"
+#endif
+template int launch_sampler_lat_act<FRL_RS_ACT>(const KArgs&, hipStream_t);
+
+}  // namespace frl

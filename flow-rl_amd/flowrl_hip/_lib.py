@@ -17,6 +17,7 @@ FRL_SOLVER_DDPM, FRL_SOLVER_DDIM, FRL_SOLVER_EULER, FRL_SOLVER_DPM2, FRL_SOLVER_
 FRL_TEMB_NONE, FRL_TEMB_POSITIONAL, FRL_TEMB_FOURIER = 0, 1, 2
 FRL_ACT = {"mish": 0, "silu": 1, "relu": 2, "gelu_tanh": 3, "gelu": 3, "tanh": 4, "elu": 5}
 FRL_DTYPE_F32, FRL_DTYPE_BF16 = 0, 1
+FRL_TILE = {"auto": 0, "throughput": 1, "latency": 2}
 
 FRL_OK, FRL_EINVAL, FRL_EUNSUPPORTED, FRL_EWORKSPACE, FRL_EHIP = 0, -1, -2, -3, -4
 
@@ -30,7 +31,7 @@ class FrlDesc(C.Structure):
         ("time_embed", C.c_int32), ("time_dim", C.c_int32), ("n_hidden", C.c_int32),
         ("hidden", C.c_int32 * FRL_MAX_HIDDEN), ("act", C.c_int32), ("clip", C.c_int32),
         ("x_min", C.c_float), ("x_max", C.c_float), ("dtype", C.c_int32), ("want_history", C.c_int32),
-        ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32),
+        ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32), ("tile_policy", C.c_int32),
     ]
 
 

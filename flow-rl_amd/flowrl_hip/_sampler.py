@@ -58,7 +58,7 @@ def _split_condition(xT: torch.Tensor, condition: Optional[torch.Tensor], partic
 
 def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, particles: int, x_dim: int,
                cond_dim: int, clip_sampler: bool, x_min, x_max, want_history: bool,
-               compute_dtype: str = "f32") -> _lib.FrlDesc:
+               compute_dtype: str = "f32", tile_policy: str = "auto") -> _lib.FrlDesc:
     pred = network.predictor
     ce = network.cond_embedding
     if ce is not None:
@@ -101,6 +101,9 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
         raise ValueError(f"compute_dtype {compute_dtype!r}: 'f32' (bit-faithful) or 'bf16' (stated-tolerance MFMA variant)")
     d.dtype = _lib.FRL_DTYPE_BF16 if compute_dtype == "bf16" else _lib.FRL_DTYPE_F32
     d.want_history = 1 if want_history else 0
+    if tile_policy not in _lib.FRL_TILE:
+        raise ValueError(f"tile_policy {tile_policy!r}: 'auto', 'throughput' (one wave per tile) or 'latency' (four waves per tile)")
+    d.tile_policy = _lib.FRL_TILE[tile_policy]
     return d
 
 
@@ -165,7 +168,7 @@ def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None
 
 
 def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip_sampler, x_min, x_max, history,
-             particles, compute_dtype="f32"):
+             particles, compute_dtype="f32", tile_policy="auto"):
     """Descriptor, parameter pointers and schedule pointers of one call (shared by forward and VJP)."""
     device = xT.device
     A = xT.shape[-1]
@@ -175,7 +178,7 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
     keep: list = []
     desc = build_desc(network, kind=kind, solver=solver, steps=steps, n_states=n_states, particles=parts, x_dim=A,
                       cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history,
-                      compute_dtype=compute_dtype)
+                      compute_dtype=compute_dtype, tile_policy=tile_policy)
     fparams = build_params(network, params, device, keep)
     fs = _lib.FrlSchedule()
     for name in ("betas", "alphas", "alpha_hats", "postvars", "ts", "mid_ts", "mid_alphas", "mid_sigmas"):
@@ -195,7 +198,7 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
 def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
-                compute_dtype: str = "f32"):
+                compute_dtype: str = "f32", tile_policy: str = "auto"):
     """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored.  ``compute_dtype`` = "bf16"
     selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful)."""
     lib = _lib.load()
@@ -207,7 +210,7 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     desc, fparams, fs, keep, B, cond2d = _marshal(
         network, params, kind=kind, solver=solver, steps=steps, xT=xT, condition=condition, sched=sched,
         clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=history, particles=particles,
-        compute_dtype=compute_dtype)
+        compute_dtype=compute_dtype, tile_policy=tile_policy)
 
     x_in = _f32c(xT.reshape(B, A), device, "xT")
     x0 = torch.empty((B, A), dtype=torch.float32, device=device)

@@ -38,13 +38,13 @@ class ContinuousNormalizingFlow:
 
     def sample(self, rng, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                params: Optional[Dict] = None, *, history: bool = False, particles: Optional[int] = None,
-               compute_dtype: str = "f32"):
+               compute_dtype: str = "f32", tile_policy: str = "auto"):
         """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps."""
         p = params if (training and params is not None) else self.params
         x1, hist = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xT=x0,
             condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
-            x_max=self.x_max, history=history, particles=particles, compute_dtype=compute_dtype)
+            x_max=self.x_max, history=history, particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy)
         return rng, x1, hist
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x1: torch.Tensor, condition: Optional[torch.Tensor] = None,

@@ -56,7 +56,7 @@ class ContinuousDDPM:
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
-               particles: Optional[int] = None, compute_dtype: str = "f32"):
+               particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto"):
         """ContinuousDDPM.sample (continuous_ddpm.py:117-222)."""
         steps = steps or self.steps
         t_schedule_n = t_schedule_n or self.t_schedule_n
@@ -79,7 +79,7 @@ class ContinuousDDPM:
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles, compute_dtype=compute_dtype)
+            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy)
         return rng, x0, hist
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,

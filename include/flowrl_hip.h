@@ -63,6 +63,10 @@ extern "C" {
 #define FRL_ACT_TANH 4      /* jax.nn.tanh  (activation.py:14) */
 #define FRL_ACT_ELU 5       /* jax.nn.elu   (activation.py:11) */
 
+#define FRL_TILE_AUTO 0       /* latency build while the batch has no more 32-chain tiles than the GPU has CUs */
+#define FRL_TILE_THROUGHPUT 1 /* one wave per tile, no barriers (csrc/sampler_rs.hip): large batches */
+#define FRL_TILE_LATENCY 2    /* four waves per tile, features split over the SIMDs (csrc/sampler_lat.hip): acting */
+
 #define FRL_DTYPE_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the bit-faithful path */
 #define FRL_DTYPE_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16) operands, f32 accumulate / activations / chain state: stated tolerance */
 
@@ -91,6 +95,7 @@ typedef struct FrlDesc {
   int32_t cond_embed;   /* 1: a cond_embedding MLP(hidden_dims=(128,128), act) (dacer.py:263-266, qvpo.py:204-207)
                            maps each raw condition row (cond_in_dim) to the cond_dim = 128 features, once per STATE */
   int32_t cond_in_dim;  /* raw observation width when cond_embed = 1 */
+  int32_t tile_policy;  /* FRL_TILE_*: which f32 kernel build runs the chains (results agree to rounding) */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a

@@ -30,6 +30,7 @@ class Case:
     seed: int = 0
     cond_embed: bool = False       # cond_embedding MLP(128,128): S is then the RAW obs width
     bf16: bool = False             # bf16-MFMA variant (product) / bf16-operand emulation (oracle)
+    tile: str = "auto"             # FrlDesc.tile_policy of the product run: auto | throughput | latency
 
     @property
     def spec(self):
@@ -105,7 +106,7 @@ def product_run(c: Case, model, xT, cond, noise, device="cuda", history=True):
     cd = None if cond is None else torch.from_numpy(cond).to(device)
     nz = torch.from_numpy(noise).to(device)
     kw = dict(history=history, particles=c.particles if c.particles > 1 else None,
-              compute_dtype="bf16" if c.bf16 else "f32")
+              compute_dtype="bf16" if c.bf16 else "f32", tile_policy=c.tile)
     if c.kind == "ddpm":
         _, x0, (xh, eh) = model.sample(None, x, cd, False, c.solver, noise=nz, **kw)
     elif c.kind == "cddpm":

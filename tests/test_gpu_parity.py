@@ -23,7 +23,21 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.fixture(params=["throughput", "latency"], autouse=True)
+def _tile_policy(request):
+    """Every case below runs under both f32 builds: one wave per tile (sampler_rs.hip) and four waves per tile
+    (sampler_lat.hip).  `auto` would pick the latency build for all of these small batches."""
+    global TILE
+    TILE = request.param
+    yield
+
+
+TILE = "auto"
+
+
 def _check(case, history=True):
+    import dataclasses
+    case = dataclasses.replace(case, tile=TILE)
     params, xT, cond, noise = H.make_inputs(case)
     ref0, refx, refe = H.oracle_run(case, params, xT, cond, noise, dtype=np.float64)
     model = H.product_model(case, params)
