@@ -26,7 +26,12 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
     if (!sampler_lat_supports(a)) { set_error("tile_policy LATENCY: this configuration has no latency build (H %d, x_dim %d, operand cond rows %d, x rows %d, evaluations %d, LDS %zu bytes)", a.H, a.A, a.C, a.XR, a.NE, lat_lds_bytes(a.NE, a.L, a.H, false)); return FRL_EUNSUPPORTED; }
     lat = true;
   } else if (tile_policy == FRL_TILE_AUTO) {
-    lat = ntiles <= device_cus() && sampler_lat_supports(a);
+    // Measured on MI355X (cfg2 geometry, scripts/sweep_tile.sh): one round of latency-build tiles (one per CU) takes
+    // 0.12 ms, one round of throughput-build tiles (four per CU) 0.38 ms.  The latency build wins whenever its
+    // rounds cost less, i.e. for small batches and for batches whose last throughput round would be mostly empty.
+    const long long cus = device_cus();
+    const long long r_lat = (ntiles + cus - 1) / cus, r_thr = (ntiles + 4 * cus - 1) / (4 * cus);
+    lat = r_lat <= 3 * r_thr && sampler_lat_supports(a);
   }
   if (lat) {
     switch (act) {
@@ -77,6 +82,9 @@ static int validate_desc(const FrlDesc* d) {
   if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
   if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
   if (d->tile_policy < FRL_TILE_AUTO || d->tile_policy > FRL_TILE_LATENCY) { set_error("tile_policy %d invalid", d->tile_policy); return FRL_EINVAL; }
+  if (d->rng_impl < FRL_RNG_NONE || d->rng_impl > FRL_RNG_THREEFRY_LEGACY) { set_error("rng_impl %d invalid", d->rng_impl); return FRL_EINVAL; }
+  if (d->rng_impl == FRL_RNG_THREEFRY_LEGACY && (long long)d->n_states * d->particles * d->x_dim > 0xFFFFFFFFll) {
+    set_error("legacy threefry layout: at most 2^32 - 1 elements per draw"); return FRL_EUNSUPPORTED; }
   if (d->cond_embed) {
     if (d->cond_dim != COND_EMBED_DIM) { set_error("cond_embed: cond_dim must be %d (MLP(128,128)), got %d", COND_EMBED_DIM, d->cond_dim); return FRL_EUNSUPPORTED; }
     if (d->cond_in_dim < 1) { set_error("cond_embed: cond_in_dim %d invalid", d->cond_in_dim); return FRL_EINVAL; }
@@ -216,11 +224,17 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   plan_from_desc(*desc, pl);
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
-  if (pl.B == 0) return FRL_OK;   // empty batch: nothing to do (reference returns empty arrays)
+  if (pl.B == 0) {   // empty batch: no chains (the reference returns empty arrays), but the rng still advances
+    if (desc->rng_impl != FRL_RNG_NONE && bufs->rng_key != nullptr)
+      return launch_rng_chain(bufs->rng_key, desc->rng_impl, pl.mode, pl.T, (uint32_t*)((float*)workspace + pl.off_keys), bufs->rng_out, (hipStream_t)hip_stream);
+    return FRL_OK;
+  }
   if (bufs->xT == nullptr || bufs->x0 == nullptr) { set_error("bufs.xT / x0 is NULL"); return FRL_EINVAL; }
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
   const bool needs_noise = (desc->kind != FRL_KIND_CNF) && desc->solver == FRL_SOLVER_DDPM;
-  if (needs_noise && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step"); return FRL_EINVAL; }
+  const bool rng = desc->rng_impl != FRL_RNG_NONE;
+  if (rng && bufs->rng_key == nullptr) { set_error("desc.rng_impl = %d but bufs.rng_key is NULL", desc->rng_impl); return FRL_EINVAL; }
+  if (needs_noise && !rng && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step (or set desc.rng_impl and bufs.rng_key)"); return FRL_EINVAL; }
   if (desc->want_history && (bufs->xt_hist == nullptr || bufs->eps_hist == nullptr)) { set_error("want_history set but xt_hist / eps_hist is NULL"); return FRL_EINVAL; }
   for (int l = 1; l < desc->n_hidden; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
@@ -231,7 +245,16 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   const float* ws = (const float*)workspace;
   KArgs a;
   memset(&a, 0, sizeof(a));
-  a.xT = bufs->xT; a.cond = bufs->cond; a.noise = needs_noise ? bufs->noise : nullptr;
+  // an explicit noise tensor wins over in-kernel draws (the rng is still advanced as the reference's scan does)
+  const bool draw = rng && needs_noise && bufs->noise == nullptr;
+  a.xT = bufs->xT; a.cond = bufs->cond; a.noise = (needs_noise && !draw) ? bufs->noise : nullptr;
+  if (rng) {
+    // the scan's split sequence: one key per iteration that draws noise, and the rng sample() returns
+    uint32_t* keys = (uint32_t*)((float*)workspace + pl.off_keys);
+    rc = launch_rng_chain(bufs->rng_key, desc->rng_impl, pl.mode, pl.T, keys, bufs->rng_out, (hipStream_t)hip_stream);
+    if (rc != FRL_OK) return rc;
+    if (draw) { a.rng_keys = keys; a.rng_impl = desc->rng_impl; }
+  }
   if (desc->cond_embed) {
     // cond_embedding MLP once per state (ddpm.py:89-90), into the workspace; the sampler then reads those rows
     float* cfeat = (float*)workspace + pl.off_cfeat;
@@ -498,6 +521,16 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
   }
   return launch_critic_select(qm, E, desc->n_states, desc->particles, pl.A, bufs->actions, bufs->gumbel, bufs->inv_temperature,
                               bufs->q, bufs->best_idx, bufs->best_action, stream);
+}
+
+int frl_random_split(const uint32_t* key, int32_t impl, int32_t num, uint32_t* out, void* hip_stream) {
+  return launch_random_split(key, impl, num, out, (hipStream_t)hip_stream);
+}
+int frl_random_normal(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream) {
+  return launch_random_fill(key, impl, n, out, true, (hipStream_t)hip_stream);
+}
+int frl_random_bits(const uint32_t* key, int32_t impl, int64_t n, uint32_t* out, void* hip_stream) {
+  return launch_random_fill(key, impl, n, out, false, (hipStream_t)hip_stream);
 }
 
 int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream) {

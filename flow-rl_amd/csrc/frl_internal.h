@@ -62,7 +62,7 @@ struct Plan {
   int mode;
   long long B;
   // workspace layout (float offsets)
-  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, off_zs, total_floats;
+  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, off_zs, off_keys, total_floats;
   size_t w0p_rows;
   // bf16 MFMA variant (32x32x16, hidden width 256): weight stream image = bf_ns chunks of 32 KB per step
   int bf16;             // 1: desc.dtype == FRL_DTYPE_BF16
@@ -117,6 +117,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p) {
   p.off_blp = take(LAST_PAD);
   p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
   p.off_zs = take(p.hoist ? (size_t)d.n_states * p.H : 0);                     // hoisted cond slice of Dense_0, one row per state
+  p.off_keys = take(d.rng_impl != FRL_RNG_NONE ? (size_t)p.NE * 2 : 0);        // per-iteration threefry keys (uint32 pairs)
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
   p.bf_nxk = (p.A <= 16 && p.C <= 32) ? 1 : 2;   // narrow instantiation <8, 2> or wide <16, 8>
   p.bf_cks = (p.bf_nxk == 1) ? 2 : 8;
@@ -139,6 +140,8 @@ struct KArgs {
   int NE;                                 // network evaluations per chain (table rows); = T except dpm2
   int AO;                                 // network outputs per chain (= A except MODE_EVAL)
   const float* wl_raw;                    // Dense_L kernel (H, AO) in place (latency kernel)
+  const uint32_t* rng_keys;               // [NE][2] iteration keys (rng_impl != FRL_RNG_NONE), else NULL
+  int rng_impl;
   int lat_tb_global;                      // latency kernel: time-bias rows read from the workspace, not staged in LDS
   const float* state_bias;                // MODE_EVAL: [n_states][H] Dense_0 accumulator init per STATE (hoisted obs rows) or NULL
   int w0p_bytes;
@@ -252,6 +255,9 @@ struct TBArgs {
   int kind, time_embed, T, D, H, A;
 };
 int launch_time_bwd(const TBArgs& a, hipStream_t stream);
+int launch_rng_chain(const uint32_t* key_in, int impl, int mode, int T, uint32_t* keys, uint32_t* rng_out, hipStream_t stream);
+int launch_random_split(const uint32_t* key, int impl, int num, uint32_t* out, hipStream_t stream);
+int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, bool normal, hipStream_t stream);
 
 int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
 int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, hipStream_t stream);

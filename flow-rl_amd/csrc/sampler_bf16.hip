@@ -26,6 +26,7 @@
 // read back with one ds_read_b128 per MFMA.  Plain f32 VALU only: v_pk_*_f32 beside bf16 MFMAs is an anti-lever
 // (measured +8.5 cycles each) — this TU is built with -fno-slp-vectorize so the compiler does not pack either.
 #include "frl_bf16.h"
+#include "frl_rng.h"
 
 namespace frl {
 
@@ -310,7 +311,11 @@ frl_sampler_bf16_kernel(const KArgs a) {
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
         // noise is read here, not a step ahead: the second wave on the SIMD covers the latency, registers are scarce
-        const float z = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        float z = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        if (a.rng_impl != FRL_RNG_NONE && in) {   // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai]
+          z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai);
+          __builtin_amdgcn_sched_barrier(0);       // one draw at a time: interleaved draws cost registers the hot loop needs
+        }
         if (a.xt_hist != nullptr && in) {
           const long long o = ((long long)j * a.B + chain) * a.A + ai;
           a.xt_hist[o] = xt;

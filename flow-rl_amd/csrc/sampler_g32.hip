@@ -27,6 +27,7 @@
 #include <utility>
 
 #include "frl_internal.h"
+#include "frl_rng.h"
 
 namespace frl {
 
@@ -315,12 +316,17 @@ frl_sampler_g32_kernel(const KArgs a) {
           a.xt_hist[o] = xt;
           a.eps_hist[o] = eps;
         }
+        float z = zr[r];
+        if (a.rng_impl != FRL_RNG_NONE && in) {   // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai]
+          z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai);
+          __builtin_amdgcn_sched_barrier(0);       // one draw at a time: interleaved draws cost registers the hot loop needs
+        }
         float xn;
         if (a.mode == MODE_DDPM_DDPM) {
           float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);   // ddpm.py:200-201
           xn = c2 * (c3 * x0h + c4 * xt);                           // ddpm.py:202-203
-          xn += c5 * zr[r];                                         // ddpm.py:206
+          xn += c5 * z;                                         // ddpm.py:206
         } else if (a.mode == MODE_DDPM_DDIM) {
           xn = c0 * (xt - c1 * eps) + c2 * eps;                     // ddpm.py:211
           if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
@@ -328,7 +334,7 @@ frl_sampler_g32_kernel(const KArgs a) {
           float x0h = (xt - c1 * eps) / c0;                         // continuous_ddpm.py:165
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * x0h + c3 * xt;                                  // :173
-          xn += c5 * zr[r];                                         // :174
+          xn += c5 * z;                                         // :174
         } else if (a.mode == MODE_CDDPM_DDIM) {
           float x0h = (xt - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);

@@ -18,6 +18,7 @@
 // up to the order of the Dense_L partial sums.  Chosen by the launcher when the batch has no more tiles than the GPU
 // has CUs (FrlDesc.tile_policy overrides).
 #include "frl_device.h"
+#include "frl_rng.h"
 
 namespace frl {
 
@@ -174,6 +175,10 @@ frl_sampler_lat_kernel(const KArgs a) {
       // ---------------- hidden layers: activations through LDS, one barrier each ------------------------
       for (int l = 1; l < a.L; ++l) {
         float* abuf = s_act + (phase++ & 1) * (H * TR);
+        // the layer's first weight k-steps are requested before the activation math, which hides their L2 latency
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
+        wv_t ring[RW];
+        sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs, voff_h, 2 * k * ROWB); });
         sfor<NBW>([&](auto JI) {
           constexpr int jb = decltype(JI)::value;
           sfor<NR>([&](auto RI) {
@@ -183,9 +188,6 @@ frl_sampler_lat_kernel(const KArgs a) {
             abuf[(((ks >> 2) * 64) + (jb & 1) * 32 + li) * 4 + (ks & 3)] = act_fn<ACT>(acc[jb][r]);
           });
         });
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
-        wv_t ring[RW];
-        sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs, voff_h, 2 * k * ROWB); });
         sfor<NR>([&](auto RI) {
           constexpr int r = decltype(RI)::value;
           const wv_t bv = *(const wv_t*)(s_bh + (l - 1) * H + FW * wave + NBW * (G::rowr(r) + 4 * ls));
@@ -243,12 +245,17 @@ frl_sampler_lat_kernel(const KArgs a) {
           a.xt_hist[o] = xt;
           a.eps_hist[o] = eps;
         }
+        float z = zr[r];
+        if (a.rng_impl != FRL_RNG_NONE && in) {   // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai]
+          z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai);
+          __builtin_amdgcn_sched_barrier(0);       // one draw at a time: interleaved draws cost registers the hot loop needs
+        }
         float xn;
         if (a.mode == MODE_DDPM_DDPM) {
           float x0h = c0 * (xt - c1 * eps);
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * (c3 * x0h + c4 * xt);
-          xn += c5 * zr[r];
+          xn += c5 * z;
         } else if (a.mode == MODE_DDPM_DDIM) {
           xn = c0 * (xt - c1 * eps) + c2 * eps;
           if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
@@ -256,7 +263,7 @@ frl_sampler_lat_kernel(const KArgs a) {
           float x0h = (xt - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
           xn = c2 * x0h + c3 * xt;
-          xn += c5 * zr[r];
+          xn += c5 * z;
         } else if (a.mode == MODE_CDDPM_DDIM) {
           float x0h = (xt - c1 * eps) / c0;
           if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);

@@ -33,6 +33,7 @@
 // loop (the LDS-DMA K-slab variant, sampler_g32.hip, loses ~1.2k cycles per 32 KB slab to DMA issue
 // and barrier skew — A/B in DESIGN.md); LDS only holds the small bias / coefficient tables.
 #include "frl_device.h"
+#include "frl_rng.h"
 
 namespace frl {
 
@@ -147,6 +148,17 @@ frl_sampler_rs_kernel(const KArgs a) {
     sfor<(EXT ? NRX : 1)>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
 
     for (int j = 0; j < a.NE; ++j) {   // one iteration per network evaluation (= per sampler step, except dpm2: two)
+      float zr[NRX];
+      if constexpr (EXT) {
+        // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai] (frl_rng.h), drawn while no accumulator is live
+        if (a.rng_impl != FRL_RNG_NONE) {
+          sfor<NRX>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            const int ai = G::rowr(r) + 4 * ls;
+            zr[r] = (valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai) : 0.0f;
+          });
+        }
+      }
       // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
       bias_init(P, s_tb + j * H);
       if constexpr (EXT) {
@@ -179,12 +191,13 @@ frl_sampler_rs_kernel(const KArgs a) {
       });
 
       // noise for this step and the first Dense_L operands: issued now, consumed after the hidden layers
-      float zr[NRX];
-      sfor<NRX>([&](auto RI) {
-        constexpr int r = decltype(RI)::value;
-        const int ai = G::rowr(r) + 4 * ls;
-        zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
-      });
+      if (!EXT || a.rng_impl == FRL_RNG_NONE) {
+        sfor<NRX>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int ai = G::rowr(r) + 4 * ls;
+          zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        });
+      }
       constexpr int NLD = NK / 4;    // Dense_L: 16-byte loads, load q covers k-steps 4q .. 4q+3
       f32x4 rl[RINGL];
       sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
@@ -354,7 +367,7 @@ static int launch_inst_v(const KArgs& a, hipStream_t stream) {
 // evaluation for critics, per-state hoisted condition rows).
 template <int TR, int H, int ACT, int NRX, int CKMAX>
 static int launch_inst(const KArgs& a, hipStream_t stream) {
-  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, true>(a, stream);
+  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.rng_impl != FRL_RNG_NONE) return launch_inst_v<TR, H, ACT, NRX, CKMAX, true>(a, stream);
   return launch_inst_v<TR, H, ACT, NRX, CKMAX, false>(a, stream);
 }
 

@@ -11,6 +11,7 @@ include/flowrl_hip.h; there is no CPU / eager fallback.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
+from . import random  # noqa: F401
 from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, PositionalEmbedding,  # noqa: F401
                      LearnableFourierEmbedding, init_params, tree_from_numpy, tree_to)
 from ._lib import FlowRLHipError, FlowRLHipUnsupported  # noqa: F401

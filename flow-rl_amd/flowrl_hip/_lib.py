@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FRL_ABI_VERSION = 2
+FRL_ABI_VERSION = 3
 FRL_MAX_HIDDEN = 8
 
 FRL_KIND_DDPM, FRL_KIND_CDDPM, FRL_KIND_CNF = 0, 1, 2
@@ -18,6 +18,7 @@ FRL_TEMB_NONE, FRL_TEMB_POSITIONAL, FRL_TEMB_FOURIER = 0, 1, 2
 FRL_ACT = {"mish": 0, "silu": 1, "relu": 2, "gelu_tanh": 3, "gelu": 3, "tanh": 4, "elu": 5}
 FRL_DTYPE_F32, FRL_DTYPE_BF16 = 0, 1
 FRL_TILE = {"auto": 0, "throughput": 1, "latency": 2}
+FRL_RNG = {"none": 0, "partitionable": 1, "legacy": 2}   # jax.random threefry layouts (include/flowrl_hip.h FRL_RNG_*)
 
 FRL_OK, FRL_EINVAL, FRL_EUNSUPPORTED, FRL_EWORKSPACE, FRL_EHIP = 0, -1, -2, -3, -4
 
@@ -31,7 +32,7 @@ class FrlDesc(C.Structure):
         ("time_embed", C.c_int32), ("time_dim", C.c_int32), ("n_hidden", C.c_int32),
         ("hidden", C.c_int32 * FRL_MAX_HIDDEN), ("act", C.c_int32), ("clip", C.c_int32),
         ("x_min", C.c_float), ("x_max", C.c_float), ("dtype", C.c_int32), ("want_history", C.c_int32),
-        ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32), ("tile_policy", C.c_int32),
+        ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32), ("tile_policy", C.c_int32), ("rng_impl", C.c_int32),
     ]
 
 
@@ -49,7 +50,8 @@ class FrlSchedule(C.Structure):
 
 
 class FrlFwdBufs(C.Structure):
-    _fields_ = [("xT", _fp), ("cond", _fp), ("noise", _fp), ("x0", _fp), ("xt_hist", _fp), ("eps_hist", _fp)]
+    _fields_ = [("xT", _fp), ("cond", _fp), ("noise", _fp), ("x0", _fp), ("xt_hist", _fp), ("eps_hist", _fp),
+                ("rng_key", _fp), ("rng_out", _fp)]
 
 
 class FrlBwdBufs(C.Structure):
@@ -105,6 +107,9 @@ EXPORTS = {
     "frl_critic_workspace_bytes": (C.c_size_t, [C.POINTER(FrlCriticDesc)]),
     "frl_critic_select": (C.c_int, [C.POINTER(FrlCriticDesc), C.POINTER(FrlCriticParams), C.POINTER(FrlSelectBufs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_random_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "frl_random_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "frl_random_bits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "frl_selftest_mfma32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

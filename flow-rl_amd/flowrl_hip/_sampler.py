@@ -12,6 +12,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
+from . import random as _random
 from .module import LearnableFourierEmbedding, PositionalEmbedding
 
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -58,7 +59,7 @@ def _split_condition(xT: torch.Tensor, condition: Optional[torch.Tensor], partic
 
 def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, particles: int, x_dim: int,
                cond_dim: int, clip_sampler: bool, x_min, x_max, want_history: bool,
-               compute_dtype: str = "f32", tile_policy: str = "auto") -> _lib.FrlDesc:
+               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: int = 0) -> _lib.FrlDesc:
     pred = network.predictor
     ce = network.cond_embedding
     if ce is not None:
@@ -104,6 +105,7 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
     if tile_policy not in _lib.FRL_TILE:
         raise ValueError(f"tile_policy {tile_policy!r}: 'auto', 'throughput' (one wave per tile) or 'latency' (four waves per tile)")
     d.tile_policy = _lib.FRL_TILE[tile_policy]
+    d.rng_impl = int(rng_impl)
     return d
 
 
@@ -168,7 +170,7 @@ def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None
 
 
 def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip_sampler, x_min, x_max, history,
-             particles, compute_dtype="f32", tile_policy="auto"):
+             particles, compute_dtype="f32", tile_policy="auto", rng_impl=0):
     """Descriptor, parameter pointers and schedule pointers of one call (shared by forward and VJP)."""
     device = xT.device
     A = xT.shape[-1]
@@ -178,7 +180,7 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
     keep: list = []
     desc = build_desc(network, kind=kind, solver=solver, steps=steps, n_states=n_states, particles=parts, x_dim=A,
                       cond_dim=cond_dim, clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, want_history=history,
-                      compute_dtype=compute_dtype, tile_policy=tile_policy)
+                      compute_dtype=compute_dtype, tile_policy=tile_policy, rng_impl=rng_impl)
     fparams = build_params(network, params, device, keep)
     fs = _lib.FrlSchedule()
     for name in ("betas", "alphas", "alpha_hats", "postvars", "ts", "mid_ts", "mid_alphas", "mid_sigmas"):
@@ -198,8 +200,11 @@ def _marshal(network, params, *, kind, solver, steps, xT, condition, sched, clip
 def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
-                compute_dtype: str = "f32", tile_policy: str = "auto"):
-    """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored.  ``compute_dtype`` = "bf16"
+                compute_dtype: str = "f32", tile_policy: str = "auto", rng_key: Optional[torch.Tensor] = None,
+                rng_impl: Optional[str] = None):
+    """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored — and, when ``rng_key`` (a (2,)
+    uint32 threefry key, flowrl_hip.random) is given, a third element: the rng the reference's sample() returns; the
+    per-step noise is then drawn in-kernel unless ``noise`` is passed.  ``compute_dtype`` = "bf16"
     selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful)."""
     lib = _lib.load()
     if not xT.is_cuda:
@@ -210,7 +215,8 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     desc, fparams, fs, keep, B, cond2d = _marshal(
         network, params, kind=kind, solver=solver, steps=steps, xT=xT, condition=condition, sched=sched,
         clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=history, particles=particles,
-        compute_dtype=compute_dtype, tile_policy=tile_policy)
+        compute_dtype=compute_dtype, tile_policy=tile_policy,
+        rng_impl=0 if rng_key is None else _random.impl_id(rng_impl))
 
     x_in = _f32c(xT.reshape(B, A), device, "xT")
     x0 = torch.empty((B, A), dtype=torch.float32, device=device)
@@ -223,6 +229,11 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
             raise ValueError(f"noise has {noise.numel()} elements, expected (T, ..., A) = {steps * B * A}")
         noise = _f32c(noise.reshape(steps, B, A), device, "noise")
         bufs.noise = noise.data_ptr()
+    rng_out = None
+    if rng_key is not None:
+        rng_key = _random.as_key(rng_key, device)
+        rng_out = torch.empty((2,), dtype=torch.uint32, device=device)
+        bufs.rng_key, bufs.rng_out = rng_key.data_ptr(), rng_out.data_ptr()
     xt_hist = eps_hist = None
     if history:
         xt_hist = torch.empty((steps, B, A), dtype=torch.float32, device=device)
@@ -238,9 +249,10 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
                                  ws.data_ptr(), ws.numel(), stream)
     _lib.check(rc)
     x0 = x0.reshape(*lead, A)
-    if history:
-        return x0, (xt_hist.reshape(steps, *lead, A), eps_hist.reshape(steps, *lead, A))
-    return x0, (None, None)
+    hist = (xt_hist.reshape(steps, *lead, A), eps_hist.reshape(steps, *lead, A)) if history else (None, None)
+    if rng_key is not None:
+        return x0, hist, rng_out
+    return x0, hist
 
 
 # ---- chain VJP -----------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import _lib
+from .. import random as _random
 from .._sampler import run_sampler, run_sampler_vjp
 from ..module import FlowBackbone, init_params
 
@@ -38,14 +39,18 @@ class ContinuousNormalizingFlow:
 
     def sample(self, rng, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                params: Optional[Dict] = None, *, history: bool = False, particles: Optional[int] = None,
-               compute_dtype: str = "f32", tile_policy: str = "auto"):
-        """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps."""
+               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None):
+        """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps.  A (2,) uint32
+        threefry key as ``rng`` is advanced as the reference's scan does (cnf.py:126) and returned; anything else is
+        returned unchanged."""
+        key = rng if _random.is_key(rng) else None
         p = params if (training and params is not None) else self.params
-        x1, hist = run_sampler(
+        out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xT=x0,
             condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
-            x_max=self.x_max, history=history, particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy)
-        return rng, x1, hist
+            x_max=self.x_max, history=history, particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy,
+            rng_key=key, rng_impl=rng_impl)
+        return (out[2] if key is not None else rng), out[0], out[1]
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x1: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gx0: bool = True,

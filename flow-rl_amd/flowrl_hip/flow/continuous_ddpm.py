@@ -9,6 +9,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from .. import _lib, schedules
+from .. import random as _random
 from .._sampler import run_sampler, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
 from .ddpm import draw_noise
@@ -56,8 +57,13 @@ class ContinuousDDPM:
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
-               particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto"):
-        """ContinuousDDPM.sample (continuous_ddpm.py:117-222)."""
+               particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
+               rng_impl: Optional[str] = None):
+        """ContinuousDDPM.sample (continuous_ddpm.py:117-222).
+        ``rng``: a (2,) uint32 threefry key (flowrl_hip.random.PRNGKey / jax.random.key_data) makes the call a
+        true rng-in / rng-out drop-in: the scan's split sequence runs on the GPU, the per-step noise is drawn in-kernel
+        (no (T, B, A) tensor) and the advanced rng is returned; ``rng_impl`` = "partitionable" (jax >= 0.5 default) or
+        "legacy".  A torch.Generator / None keeps the torch-drawn noise path and is returned unchanged."""
         steps = steps or self.steps
         t_schedule_n = t_schedule_n or self.t_schedule_n
         solver = solver or self.solver
@@ -69,18 +75,19 @@ class ContinuousDDPM:
         dev = xT.device
         to = lambda v: torch.from_numpy(v).to(dev)
         p = params if (training and params is not None) else self.params
-        if solver == "ddpm" and noise is None:
+        key = rng if _random.is_key(rng) else None
+        if solver == "ddpm" and noise is None and key is None:
             noise = draw_noise(rng, (steps, *xT.shape), xT.device)
         sched = {"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)}
         if solver == "dpm2":
             mid, mal, msg = schedules.continuous_midpoints(ts, self.noise_schedule_func)
             sched.update(mid_ts=to(mid), mid_alphas=to(mal), mid_sigmas=to(msg))
-        x0, hist = run_sampler(
+        out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy)
-        return rng, x0, hist
+            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl)
+        return (out[2] if key is not None else rng), out[0], out[1]
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,

@@ -13,6 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from .. import _lib, schedules
+from .. import random as _random
 from .._sampler import run_sampler, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
 
@@ -65,26 +66,31 @@ class DDPM:
 
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: str = "ddpm", params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None,
-               history: bool = False, particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto"
-               ) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+               history: bool = False, particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
+               rng_impl: Optional[str] = None) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
         """DDPM.sample (ddpm.py:173-221).  Extra keyword-only arguments:
         ``noise`` (T, *xT.shape): the per-iteration N(0, I) draws (iteration j <-> t = T - j);
         ``history``: also return (xt_hist, eps_hist) (ddpm.py:217); ``particles``: chains per condition
         row when ``condition`` is passed un-repeated; ``compute_dtype`` = "bf16" selects the bf16-MFMA variant (stated
-        tolerance, see tests/test_gpu_bf16.py) instead of the bit-faithful f32 kernel."""
+        tolerance, see tests/test_gpu_bf16.py) instead of the bit-faithful f32 kernel.
+        ``rng``: a (2,) uint32 threefry key (flowrl_hip.random.PRNGKey / jax.random.key_data) makes the call a
+        true rng-in / rng-out drop-in: the scan's split sequence runs on the GPU, the per-step noise is drawn in-kernel
+        (no (T, B, A) tensor) and the advanced rng is returned; ``rng_impl`` = "partitionable" (jax >= 0.5 default) or
+        "legacy".  A torch.Generator / None keeps the torch-drawn noise path and is returned unchanged."""
         if solver not in SUPPORTED_SOLVERS:
             raise NotImplementedError(f"Unsupported solver {solver} for {type(self)}")
         p = params if (training and params is not None) else self.params   # ddpm.py:191-196
-        if solver == "ddpm" and noise is None:
+        key = rng if _random.is_key(rng) else None
+        if solver == "ddpm" and noise is None and key is None:
             noise = draw_noise(rng, (self.steps, *xT.shape), xT.device)
-        x0, hist = run_sampler(
+        out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_DDPM,
             solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
             steps=self.steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy)
-        return rng, x0, hist
+            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl)
+        return (out[2] if key is not None else rng), out[0], out[1]
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: str = "ddpm", params: Optional[Dict] = None, *, particles: Optional[int] = None,

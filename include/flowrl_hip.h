@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FRL_ABI_VERSION 2
+#define FRL_ABI_VERSION 3
 #define FRL_MAX_HIDDEN 8 /* hidden Dense layers of the predictor MLP (mlp.py:25) */
 
 /* error codes */
@@ -63,9 +63,15 @@ extern "C" {
 #define FRL_ACT_TANH 4      /* jax.nn.tanh  (activation.py:14) */
 #define FRL_ACT_ELU 5       /* jax.nn.elu   (activation.py:11) */
 
-#define FRL_TILE_AUTO 0       /* latency build while the batch has no more 32-chain tiles than the GPU has CUs */
+#define FRL_TILE_AUTO 0       /* latency build when its rounds (one 32-chain tile per CU) cost less than the throughput build's (four per CU) */
 #define FRL_TILE_THROUGHPUT 1 /* one wave per tile, no barriers (csrc/sampler_rs.hip): large batches */
 #define FRL_TILE_LATENCY 2    /* four waves per tile, features split over the SIMDs (csrc/sampler_lat.hip): acting */
+
+/* Where the per-step N(0, I) draws of the ddpm solvers come from (FrlDesc.rng_impl).  The reference draws them with
+ * jax.random inside the scan (ddpm.py:188,204-206; continuous_ddpm.py:161,174,190; cnf.py:126 for the key sequence). */
+#define FRL_RNG_NONE 0                   /* the caller supplies bufs.noise (T, B, A)                                   */
+#define FRL_RNG_THREEFRY_PARTITIONABLE 1 /* in-kernel threefry2x32, jax_threefry_partitionable=True (jax >= 0.5.0 default) */
+#define FRL_RNG_THREEFRY_LEGACY 2        /* in-kernel threefry2x32, the pre-0.5.0 default key / counter layout           */
 
 #define FRL_DTYPE_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the bit-faithful path */
 #define FRL_DTYPE_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16) operands, f32 accumulate / activations / chain state: stated tolerance */
@@ -96,6 +102,8 @@ typedef struct FrlDesc {
                            maps each raw condition row (cond_in_dim) to the cond_dim = 128 features, once per STATE */
   int32_t cond_in_dim;  /* raw observation width when cond_embed = 1 */
   int32_t tile_policy;  /* FRL_TILE_*: which f32 kernel build runs the chains (results agree to rounding) */
+  int32_t rng_impl;     /* FRL_RNG_*: with a threefry layout, bufs.rng_key replaces bufs.noise and the call also produces
+                           the rng the reference's sample() returns (bufs.rng_out), for every solver */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a
@@ -139,6 +147,9 @@ typedef struct FrlFwdBufs {
   float* x0;          /* (B, A)  result                                                    */
   float* xt_hist;     /* (T, B, A) or NULL: input of iteration j  (history[0], ddpm.py:217)  */
   float* eps_hist;    /* (T, B, A) or NULL: net output of iteration j (history[1])           */
+  const uint32_t* rng_key; /* device (2,) uint32: the `rng` argument of sample() (a raw threefry key, as
+                              jax.random.key_data gives it); used when desc.rng_impl != FRL_RNG_NONE, else ignored */
+  uint32_t* rng_out;       /* device (2,) uint32 or NULL: the rng sample() returns (after the scan's splits)     */
 } FrlFwdBufs;
 
 /* FRL_OK if this build has a kernel for `desc`, else FRL_EINVAL / FRL_EUNSUPPORTED (message set). */
@@ -253,6 +264,15 @@ double frl_hoisted_flops(const FrlDesc* desc);
 const char* frl_last_error(void);
 
 /* ABI version this library was built with. */
+/* jax.random pieces for the callers either side of the sampler (dql.py:142-146 draws xT with its own split before
+ * calling sample): keys are device (2,) uint32, impl is FRL_RNG_THREEFRY_*.
+ *   frl_random_split   out (num, 2) uint32 = jax.random.split(key, num)
+ *   frl_random_normal  out (n,) f32        = jax.random.normal(key, shape) flattened, n = prod(shape)
+ *   frl_random_bits    out (n,) uint32     = jax.random.bits(key, shape) flattened                               */
+int frl_random_split(const uint32_t* key, int32_t impl, int32_t num, uint32_t* out, void* hip_stream);
+int frl_random_normal(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream);
+int frl_random_bits(const uint32_t* key, int32_t impl, int64_t n, uint32_t* out, void* hip_stream);
+
 int frl_abi_version(void);
 
 /* Hardware self-test of the MFMA operand / accumulator lane maps the kernel relies on:
