@@ -88,6 +88,10 @@ def sample(model, w, xT, cond, noise):
     cd = w.get("dtype", "f32")
     if w["kind"] == "cnf":
         return model.sample(None, xT, cond, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"))[1]
+    if w.get("rng", "none") != "none":
+        from flowrl_hip import random as fr
+        key = fr.PRNGKey(0, xT.device)
+        return model.sample(key, xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"])[1]
     return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"))[1]
 
 
@@ -129,7 +133,8 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     desc = _sampler.build_desc(model.network, kind=kind, solver=_lib.FRL_SOLVER_EULER if w["kind"] == "cnf" else _lib.FRL_SOLVER_DDPM,
                                steps=w["T"], n_states=w["B"] // w["particles"], particles=w["particles"], x_dim=w["A"],
                                cond_dim=w["S"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"], want_history=False,
-                               compute_dtype=w.get("dtype", "f32"), tile_policy=w.get("tile_policy", "auto"))
+                               compute_dtype=w.get("dtype", "f32"), tile_policy=w.get("tile_policy", "auto"),
+                               rng_impl=_lib.FRL_RNG[w.get("rng", "none")])
     fp = _sampler.build_params(model.network, model.params, dev, keep)
     fs = _lib.FrlSchedule()
     if w["kind"] == "ddpm":
@@ -145,7 +150,13 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     x0 = torch.empty_like(xT)
     bufs = _lib.FrlFwdBufs()
     bufs.xT, bufs.cond, bufs.x0 = xT.data_ptr(), cond.data_ptr(), x0.data_ptr()
-    if noise is not None:
+    if w.get("rng", "none") != "none":
+        from flowrl_hip import random as fr
+        key = fr.PRNGKey(0, dev)
+        rng_out = torch.empty_like(key)
+        keep += [key, rng_out]
+        bufs.rng_key, bufs.rng_out = key.data_ptr(), rng_out.data_ptr()
+    elif noise is not None:
         bufs.noise = noise.data_ptr()
     need = lib.frl_workspace_bytes(C.byref(desc))
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -243,6 +254,8 @@ def main():
                     help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (H = 256 workloads)")
     ap.add_argument("--tile-policy", default="auto", choices=["auto", "throughput", "latency"],
                     help="f32 forward kernel build (FrlDesc.tile_policy); auto = latency build for small batches")
+    ap.add_argument("--rng", default="none", choices=["none", "partitionable", "legacy"],
+                    help="draw the per-step noise in-kernel from a threefry key (FrlDesc.rng_impl) instead of reading a (T, B, A) tensor")
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
@@ -266,6 +279,7 @@ def main():
         w["B"] = args.batch
     w["dtype"] = args.dtype
     w["tile_policy"] = args.tile_policy
+    w["rng"] = args.rng
     if args.act:
         w["act"] = args.act
     if args.layers > 0:
@@ -342,11 +356,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
-                       "chains_per_s": value / T, "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
+                       "chains_per_s": value / T, "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": None if (vjp or args.act or args.layers or args.dtype != "f32") else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",
-                         "algorithmic_hbm_bytes": B * (4 * (2 * A + (T * A if w["kind"] != "cnf" else 0)) + 4 * S // w["particles"]),
+                         "algorithmic_hbm_bytes": B * (4 * (2 * A + (T * A if (w["kind"] != "cnf" and args.rng == "none") else 0)) + 4 * S // w["particles"]),
                          "kernel": kname, "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_hoisted_not_credited": getattr(kernel_only_ms, "hoisted", 0.0) * (3.0 if vjp else 1.0),
                          "flops_executed_mfma": flops_exec,

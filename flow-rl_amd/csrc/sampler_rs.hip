@@ -152,10 +152,11 @@ frl_sampler_rs_kernel(const KArgs a) {
       if constexpr (EXT) {
         // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai] (frl_rng.h), drawn while no accumulator is live
         if (a.rng_impl != FRL_RNG_NONE) {
+          const bool used = s_coef[j * COEF_STRIDE + 5] != 0.0f;   // c5 = 0: the last iteration multiplies its draw by 0 (ddpm.py:206)
           sfor<NRX>([&](auto RI) {
             constexpr int r = decltype(RI)::value;
             const int ai = G::rowr(r) + 4 * ls;
-            zr[r] = (valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai) : 0.0f;
+            zr[r] = (used && valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai) : 0.0f;
           });
         }
       }
