@@ -87,18 +87,18 @@ def sample(model, w, xT, cond, noise):
     p = w["particles"] if w["particles"] > 1 else None
     cd = w.get("dtype", "f32")
     if w["kind"] == "cnf":
-        return model.sample(None, xT, cond, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"))[1]
+        return model.sample(None, xT, cond, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), cache_prepare=w.get("cache_prepare", False))[1]
     if w.get("rng", "none") != "none":
         from flowrl_hip import random as fr
         key = fr.PRNGKey(0, xT.device)
-        return model.sample(key, xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"])[1]
-    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"))[1]
+        return model.sample(key, xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"], cache_prepare=w.get("cache_prepare", False))[1]
+    return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), cache_prepare=w.get("cache_prepare", False))[1]
 
 
 def vjp_step(model, w, xT, cond, noise, g):
     """One DQL actor-update worth of sampler work: forward keeping history[0], then the chain VJP."""
     cd = w.get("dtype", "f32")
-    _, x0, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd)
+    _, x0, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, cache_prepare=False)
     grads, _ = model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
     return x0, grads
 
@@ -107,7 +107,7 @@ def vjp_only_ms(model, w, xT, cond, noise, g, iters):
     """Average duration of the backward call alone (frl_sampler_bwd: prepare + sweep + dW kernels, plus the host's
     O(T D^2) time-branch autograd), events on the launch stream."""
     cd = w.get("dtype", "f32")
-    _, _, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd)
+    _, _, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, cache_prepare=False)
     for _ in range(2):
         model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -254,6 +254,9 @@ def main():
                     help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (H = 256 workloads)")
     ap.add_argument("--tile-policy", default="auto", choices=["auto", "throughput", "latency"],
                     help="f32 forward kernel build (FrlDesc.tile_policy); auto = latency build for small batches")
+    ap.add_argument("--cache-prepare", action="store_true",
+                    help="let the host wrapper reuse the prepared tables / packed weights across calls (acting between two "
+                         "optimizer steps); off by default so that every timed step runs the batch-invariant prepare kernel too")
     ap.add_argument("--rng", default="none", choices=["none", "partitionable", "legacy"],
                     help="draw the per-step noise in-kernel from a threefry key (FrlDesc.rng_impl) instead of reading a (T, B, A) tensor")
     ap.add_argument("--act", default="", help="ablation: override the activation")
@@ -280,6 +283,7 @@ def main():
     w["dtype"] = args.dtype
     w["tile_policy"] = args.tile_policy
     w["rng"] = args.rng
+    w["cache_prepare"] = bool(args.cache_prepare)
     if args.act:
         w["act"] = args.act
     if args.layers > 0:
@@ -356,7 +360,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
-                       "chains_per_s": value / T, "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
+                       "chains_per_s": value / T, "prepare": "cached across calls" if args.cache_prepare else "every call", "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": None if (vjp or args.act or args.layers or args.dtype != "f32") else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",

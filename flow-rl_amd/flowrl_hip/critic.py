@@ -115,7 +115,7 @@ def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor],
     if need == 0:
         _lib.check(lib.frl_critic_select(C.byref(d), C.byref(fp), C.byref(bufs), None, 0, None))
         raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "this critic configuration has no kernel")
-    ws = _workspace(need, dev)
+    ws = _workspace(need, dev, torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
         rc = lib.frl_critic_select(C.byref(d), C.byref(fp), C.byref(bufs), ws.data_ptr(), ws.numel(),
                                    torch.cuda.current_stream(dev).cuda_stream)

@@ -54,11 +54,28 @@ class ContinuousDDPM:
     def replace(self, **kw) -> "ContinuousDDPM":
         return replace(self, **kw)
 
+    def _device_tables(self, steps: int, t_schedule_n: float, midpoints: bool, dev) -> Dict[str, torch.Tensor]:
+        """The per-call tables of continuous_ddpm.py:134-138 (and the dpm2 midpoints, :181-184), built once per
+        (steps, t_schedule_n, device) and kept on the GPU: the reference rebuilds them inside every jitted call, where
+        XLA constant-folds them."""
+        cache = self.__dict__.setdefault("_tables", {})
+        key = (steps, float(t_schedule_n), bool(midpoints), str(dev))
+        sched = cache.get(key)
+        if sched is None:
+            to = lambda v: torch.from_numpy(v).to(dev)
+            ts, ah, al, be = schedules.continuous_tables(steps, self.noise_schedule_func, self.t_diffusion, t_schedule_n)
+            sched = {"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)}
+            if midpoints:
+                mid, mal, msg = schedules.continuous_midpoints(ts, self.noise_schedule_func)
+                sched.update(mid_ts=to(mid), mid_alphas=to(mal), mid_sigmas=to(msg))
+            cache[key] = sched
+        return sched
+
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
                particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None):
+               rng_impl: Optional[str] = None, cache_prepare: bool = True):
         """ContinuousDDPM.sample (continuous_ddpm.py:117-222).
         ``rng``: a (2,) uint32 threefry key (flowrl_hip.random.PRNGKey / jax.random.key_data) makes the call a
         true rng-in / rng-out drop-in: the scan's split sequence runs on the GPU, the per-step noise is drawn in-kernel
@@ -71,22 +88,17 @@ class ContinuousDDPM:
                       "dpm++2m": _lib.FRL_SOLVER_DPMPP2M}
         if solver not in solver_ids:
             raise NotImplementedError(f"Unsupported solver: {solver}")       # continuous_ddpm.py:215
-        ts, ah, al, be = schedules.continuous_tables(steps, self.noise_schedule_func, self.t_diffusion, t_schedule_n)
         dev = xT.device
-        to = lambda v: torch.from_numpy(v).to(dev)
         p = params if (training and params is not None) else self.params
         key = rng if _random.is_key(rng) else None
         if solver == "ddpm" and noise is None and key is None:
             noise = draw_noise(rng, (steps, *xT.shape), xT.device)
-        sched = {"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)}
-        if solver == "dpm2":
-            mid, mal, msg = schedules.continuous_midpoints(ts, self.noise_schedule_func)
-            sched.update(mid_ts=to(mid), mid_alphas=to(mal), mid_sigmas=to(msg))
+        sched = self._device_tables(steps, t_schedule_n, solver == "dpm2", dev)
         out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl)
+            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare)
         return (out[2] if key is not None else rng), out[0], out[1]
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
