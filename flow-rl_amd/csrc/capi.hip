@@ -31,7 +31,7 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
     // rounds cost less, i.e. for small batches and for batches whose last throughput round would be mostly empty.
     const long long cus = device_cus();
     const long long r_lat = (ntiles + cus - 1) / cus, r_thr = (ntiles + 4 * cus - 1) / (4 * cus);
-    lat = r_lat <= 3 * r_thr && sampler_lat_supports(a);
+    lat = r_lat <= 3 * r_thr && sampler_lat_supports(a) && a.ws_ln == nullptr;
   }
   if (lat) {
     switch (act) {
@@ -82,6 +82,11 @@ static int validate_desc(const FrlDesc* d) {
   if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
   if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
   if (d->tile_policy < FRL_TILE_AUTO || d->tile_policy > FRL_TILE_LATENCY) { set_error("tile_policy %d invalid", d->tile_policy); return FRL_EINVAL; }
+  if (d->layer_norm != 0 && d->layer_norm != 1) { set_error("layer_norm %d invalid", d->layer_norm); return FRL_EINVAL; }
+  if (d->layer_norm) {
+    if (d->dtype != FRL_DTYPE_F32) { set_error("layer_norm: f32 kernel only"); return FRL_EUNSUPPORTED; }
+    if (d->tile_policy == FRL_TILE_LATENCY) { set_error("layer_norm: the latency build has no LayerNorm pass (use AUTO / THROUGHPUT)"); return FRL_EUNSUPPORTED; }
+  }
   if (d->rng_impl < FRL_RNG_NONE || d->rng_impl > FRL_RNG_THREEFRY_LEGACY) { set_error("rng_impl %d invalid", d->rng_impl); return FRL_EINVAL; }
   if (d->rng_impl == FRL_RNG_THREEFRY_LEGACY && (long long)d->n_states * d->particles * d->x_dim > 0xFFFFFFFFll) {
     set_error("legacy threefry layout: at most 2^32 - 1 elements per draw"); return FRL_EUNSUPPORTED; }
@@ -211,6 +216,16 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
   pa.kind = desc->kind;
   pa.time_embed = desc->time_embed;
   rc = launch_prepare(pa, (hipStream_t)hip_stream);
+  if (rc == FRL_OK && desc->layer_norm) {
+    // LayerNorm scale | bias rows of every hidden layer, gathered into one [L][2][H] image the kernel stages in LDS
+    float* ln = (float*)workspace + pl.off_ln;
+    for (int l = 0; l < pl.L && rc == FRL_OK; ++l) {
+      if (params->ln_scale[l] == nullptr || params->ln_bias[l] == nullptr) { set_error("params.ln_scale/ln_bias[%d] is NULL (desc.layer_norm = 1)", l); return FRL_EINVAL; }
+      hipError_t e = hipMemcpyAsync(ln + (size_t)(2 * l) * pl.H, params->ln_scale[l], pl.H * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(ln + (size_t)(2 * l + 1) * pl.H, params->ln_bias[l], pl.H * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream);
+      if (e != hipSuccess) { set_error("LayerNorm rows: %s", hipGetErrorString(e)); rc = FRL_EHIP; }
+    }
+  }
   if (rc == FRL_OK && pl.bf16) rc = launch_prepare_bf16(*params, pl, (float*)workspace, (hipStream_t)hip_stream);
   return rc;
 }
@@ -277,6 +292,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
+  a.ws_ln = desc->layer_norm ? ws + pl.off_ln : nullptr;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.NE = pl.NE; a.AO = pl.AO;
   if (pl.hoist) a.C = 0;
@@ -290,7 +306,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   }
   // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)
   static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
-  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER && !pl.hoist)
+  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER && !pl.hoist && !desc->layer_norm)
     return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
   a.wl_raw = params->kernel[desc->n_hidden];
   return launch_f32_network(a, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
@@ -309,6 +325,7 @@ static int validate_bwd(const FrlDesc* d) {
   Plan pl;
   plan_from_desc(*d, pl);
   if (pl.mode > MODE_CNF_EULER) { set_error("VJP: solvers dpm2 / dpm++2m have no backward kernel"); return FRL_EUNSUPPORTED; }
+  if (d->layer_norm) { set_error("VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->dtype == FRL_DTYPE_BF16) {
     // bf16-MFMA VJP (csrc/sampler_bwd_bf16.hip): the narrow instantiation of the bf16 forward kernel
     if (pl.A > 16 || pl.C > 32 || pl.A + pl.C > 32) { set_error("bf16 VJP: x_dim <= 16 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }

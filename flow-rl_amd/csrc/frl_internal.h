@@ -62,7 +62,7 @@ struct Plan {
   int mode;
   long long B;
   // workspace layout (float offsets)
-  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, off_zs, off_keys, total_floats;
+  size_t off_coef, off_tb, off_w0p, off_wlp, off_wlq, off_blp, off_cfeat, off_zs, off_keys, off_ln, total_floats;
   size_t w0p_rows;
   // bf16 MFMA variant (32x32x16, hidden width 256): weight stream image = bf_ns chunks of 32 KB per step
   int bf16;             // 1: desc.dtype == FRL_DTYPE_BF16
@@ -118,6 +118,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p) {
   p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
   p.off_zs = take(p.hoist ? (size_t)d.n_states * p.H : 0);                     // hoisted cond slice of Dense_0, one row per state
   p.off_keys = take(d.rng_impl != FRL_RNG_NONE ? (size_t)p.NE * 2 : 0);        // per-iteration threefry keys (uint32 pairs)
+  p.off_ln = take(d.layer_norm ? (size_t)p.L * 2 * p.H : 0);                    // LayerNorm scale | bias rows, [L][2][H]
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
   p.bf_nxk = (p.A <= 16 && p.C <= 32) ? 1 : 2;   // narrow instantiation <8, 2> or wide <16, 8>
   p.bf_cks = (p.bf_nxk == 1) ? 2 : 8;
@@ -142,6 +143,7 @@ struct KArgs {
   const float* wl_raw;                    // Dense_L kernel (H, AO) in place (latency kernel)
   const uint32_t* rng_keys;               // [NE][2] iteration keys (rng_impl != FRL_RNG_NONE), else NULL
   int rng_impl;
+  const float* ws_ln;                     // [L][2][H] LayerNorm scale | bias of every hidden layer, or NULL (no LayerNorm)
   int lat_tb_global;                      // latency kernel: time-bias rows read from the workspace, not staged in LDS
   const float* state_bias;                // MODE_EVAL: [n_states][H] Dense_0 accumulator init per STATE (hoisted obs rows) or NULL
   int w0p_bytes;

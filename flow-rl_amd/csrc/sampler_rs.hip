@@ -69,6 +69,11 @@ frl_sampler_rs_kernel(const KArgs a) {
   }
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
   for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
+  float* s_ln = s_coef + a.NE * COEF_STRIDE;          // EXT, LayerNorm backbones only: [L][2][H] scale | bias rows
+  if constexpr (EXT) {
+    if (a.ws_ln != nullptr)
+      for (int idx = tid; idx < a.L * 2 * H; idx += blockDim.x) s_ln[idx] = a.ws_ln[idx];
+  }
   __syncthreads();
 
   // per-lane parts of the weight addresses (bytes)
@@ -86,6 +91,42 @@ frl_sampler_rs_kernel(const KArgs a) {
         constexpr int r = decltype(RI)::value;
         const f32x4 bv = *(const f32x4*)(sb + g * GW + 4 * (G::rowr(r) + 4 * ls));
         sfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; Q[g * 4 + j][r] = bv[j]; });
+      });
+    });
+  };
+
+  // flax.linen.LayerNorm over the H features of every chain, in place on a finished pre-activation tile (mlp.py:26-29:
+  // Dense -> LayerNorm -> act): mean and E[x^2] over the lane's own registers, combined across the 64 / TR lanes that
+  // hold the other feature rows of the same chain; eps = 1e-6.
+  auto ln_pass = [&](acc_t (&Q)[NB], const float* sl) {
+    float s1 = 0.0f;
+    sfor<NB>([&](auto BI) {
+      constexpr int b = decltype(BI)::value;
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; s1 += Q[b][r]; });
+    });
+#pragma unroll
+    for (int m = TR; m < 64; m <<= 1) s1 += __shfl_xor(s1, m);
+    const float mean = s1 * (1.0f / H);
+    // the variance about the mean (two passes over registers): the same quantity as flax's E[x^2] - E[x]^2 without
+    // its float32 cancellation, so the result sits closer to the exact value than the reference's own
+    float s2 = 0.0f;
+    sfor<NB>([&](auto BI) {
+      constexpr int b = decltype(BI)::value;
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; const float v = Q[b][r] - mean; s2 = fmaf(v, v, s2); });
+    });
+#pragma unroll
+    for (int m = TR; m < 64; m <<= 1) s2 += __shfl_xor(s2, m);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / H) + 1e-6f);
+    sfor<NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      sfor<NR>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const f32x4 sc = *(const f32x4*)(sl + g * GW + 4 * (G::rowr(r) + 4 * ls));
+        const f32x4 bi = *(const f32x4*)(sl + H + g * GW + 4 * (G::rowr(r) + 4 * ls));
+        sfor<4>([&](auto JI) {
+          constexpr int j = decltype(JI)::value;
+          Q[g * 4 + j][r] = (Q[g * 4 + j][r] - mean) * (rstd * sc[j]) + bi[j];
+        });
       });
     });
   };
@@ -199,6 +240,7 @@ frl_sampler_rs_kernel(const KArgs a) {
           zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         });
       }
+      if constexpr (EXT) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
       constexpr int NLD = NK / 4;    // Dense_L: 16-byte loads, load q covers k-steps 4q .. 4q+3
       f32x4 rl[RINGL];
       sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
@@ -235,6 +277,7 @@ frl_sampler_rs_kernel(const KArgs a) {
           bop = bn1; bn1 = bn2;
         });
         sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; P[b] = Q[b]; });
+        if constexpr (EXT) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
       }
 
       // next step's (or next tile's) first Dense_0 operands: in flight under Dense_L and the epilogue
@@ -347,7 +390,8 @@ static int launch_inst_v(const KArgs& a, hipStream_t stream) {
   if (nw == 3) nw = 4;
   long long nwg = (n_wt + nw - 1) / nw;
   const int grid = (int)(nwg < ncu ? nwg : ncu);
-  const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE);
+  const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE +
+                                      (a.ws_ln != nullptr ? (size_t)a.L * 2 * H : 0));
   if (lds > 160 * 1024) { set_error("sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
   static thread_local size_t configured[16] = {0};
   int dev = 0;
@@ -368,7 +412,7 @@ static int launch_inst_v(const KArgs& a, hipStream_t stream) {
 // evaluation for critics, per-state hoisted condition rows).
 template <int TR, int H, int ACT, int NRX, int CKMAX>
 static int launch_inst(const KArgs& a, hipStream_t stream) {
-  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.rng_impl != FRL_RNG_NONE) return launch_inst_v<TR, H, ACT, NRX, CKMAX, true>(a, stream);
+  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, true>(a, stream);
   return launch_inst_v<TR, H, ACT, NRX, CKMAX, false>(a, stream);
 }
 

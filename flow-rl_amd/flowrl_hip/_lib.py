@@ -32,7 +32,7 @@ class FrlDesc(C.Structure):
         ("time_embed", C.c_int32), ("time_dim", C.c_int32), ("n_hidden", C.c_int32),
         ("hidden", C.c_int32 * FRL_MAX_HIDDEN), ("act", C.c_int32), ("clip", C.c_int32),
         ("x_min", C.c_float), ("x_max", C.c_float), ("dtype", C.c_int32), ("want_history", C.c_int32),
-        ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32), ("tile_policy", C.c_int32), ("rng_impl", C.c_int32),
+        ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32), ("tile_policy", C.c_int32), ("rng_impl", C.c_int32), ("layer_norm", C.c_int32),
     ]
 
 
@@ -41,6 +41,7 @@ class FrlParams(C.Structure):
         ("time_kernel", _fp), ("tmlp_kernel", _fp * 2), ("tmlp_bias", _fp * 2),
         ("kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("bias", _fp * (FRL_MAX_HIDDEN + 1)),
         ("cond_kernel", _fp * 2), ("cond_bias", _fp * 2),
+        ("ln_scale", _fp * FRL_MAX_HIDDEN), ("ln_bias", _fp * FRL_MAX_HIDDEN),
     ]
 
 

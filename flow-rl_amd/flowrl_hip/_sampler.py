@@ -82,8 +82,8 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
                 or ce.act_name != pred.act_name):
             raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED,
                                             "cond_embedding must be MLP(hidden_dims=(128, 128), activation=<predictor's>) as in the reference agents")
-    if pred.layer_norm or (pred.dropout and pred.dropout > 0):
-        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "layer_norm / dropout>0 backbones are outside the fused path")
+    if pred.dropout and pred.dropout > 0:
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "dropout>0 backbones are outside the fused path")
     if len(pred.hidden_dims) < 1 or len(pred.hidden_dims) > _lib.FRL_MAX_HIDDEN:
         raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, f"{len(pred.hidden_dims)} hidden layers")
     d = _lib.FrlDesc()
@@ -121,6 +121,7 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
         raise ValueError(f"tile_policy {tile_policy!r}: 'auto', 'throughput' (one wave per tile) or 'latency' (four waves per tile)")
     d.tile_policy = _lib.FRL_TILE[tile_policy]
     d.rng_impl = int(rng_impl)
+    d.layer_norm = 1 if pred.layer_norm else 0     # Dense -> LayerNorm -> act (mlp.py:26-29)
     return d
 
 
@@ -149,6 +150,10 @@ def build_params(network, params: Dict, device: torch.device, keep: list) -> _li
     for i in range(n + 1):
         fp.kernel[i] = leaf((network.predictor_name, f"Dense_{i}", "kernel"))
         fp.bias[i] = leaf((network.predictor_name, f"Dense_{i}", "bias"))
+    if network.predictor.layer_norm:      # flax auto-names the LayerNorm of hidden layer i "LayerNorm_i"
+        for i in range(n):
+            fp.ln_scale[i] = leaf((network.predictor_name, f"LayerNorm_{i}", "scale"))
+            fp.ln_bias[i] = leaf((network.predictor_name, f"LayerNorm_{i}", "bias"))
     if network.cond_embedding is not None:
         for i in range(2):
             fp.cond_kernel[i] = leaf(("cond_embedding", f"Dense_{i}", "kernel"))
@@ -173,6 +178,11 @@ def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None
         if tuple(k.shape) != (dims[i], dims[i + 1]) or tuple(b.shape) != (dims[i + 1],):
             raise ValueError(f"{network.predictor_name}/Dense_{i}: kernel {tuple(k.shape)} bias {tuple(b.shape)}, "
                              f"expected {(dims[i], dims[i + 1])} / {(dims[i + 1],)} (input order x | time | cond)")
+    if network.predictor.layer_norm:
+        for i, h in enumerate(network.predictor.hidden_dims):
+            ln = pp.get(f"LayerNorm_{i}")
+            if ln is None or tuple(ln["scale"].shape) != (h,) or tuple(ln["bias"].shape) != (h,):
+                raise ValueError(f"{network.predictor_name}/LayerNorm_{i}: scale / bias of shape ({h},) expected (MLP(layer_norm=True))")
     if te is not None:
         for i in range(2):
             k = params["MLP_0"][f"Dense_{i}"]["kernel"]

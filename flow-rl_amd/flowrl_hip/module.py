@@ -110,8 +110,8 @@ def init_params(network, x_dim: int, cond_dim: int, seed: int = 0, bias_std: flo
     ``bias_std`` > 0 draws N(0, bias_std^2) biases for tests).  Mirrors ``network.init`` in
     Model.create (module/model.py:42) for the inputs (x (1,A), t (1,1), cond (1,C))."""
     pred = network.predictor
-    if pred.layer_norm or (pred.dropout and pred.dropout > 0):
-        raise NotImplementedError("layer_norm / dropout backbones are outside the fused path")
+    if pred.dropout and pred.dropout > 0:
+        raise NotImplementedError("dropout backbones are outside the fused path")
     gen = torch.Generator().manual_seed(seed)
     p: Dict = {}
     te = network.time_embedding
@@ -128,6 +128,11 @@ def init_params(network, x_dim: int, cond_dim: int, seed: int = 0, bias_std: flo
         cond_dim = cdims[-1]
     dims = [x_dim + d_time + cond_dim, *pred.hidden_dims, x_dim]
     p[network.predictor_name] = {f"Dense_{i}": _dense(gen, dims[i], dims[i + 1], bias_std) for i in range(len(dims) - 1)}
+    if pred.layer_norm:   # flax.linen.LayerNorm: scale = ones, bias = zeros (bias_std > 0 perturbs both, for tests)
+        for i, h in enumerate(pred.hidden_dims):
+            sc = torch.ones(h) if bias_std == 0.0 else 1.0 + bias_std * torch.randn(h, generator=gen)
+            bi = torch.zeros(h) if bias_std == 0.0 else bias_std * torch.randn(h, generator=gen)
+            p[network.predictor_name][f"LayerNorm_{i}"] = {"scale": sc.to(torch.float32), "bias": bi.to(torch.float32)}
     return tree_to(p, device)
 
 

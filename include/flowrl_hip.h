@@ -104,6 +104,8 @@ typedef struct FrlDesc {
   int32_t tile_policy;  /* FRL_TILE_*: which f32 kernel build runs the chains (results agree to rounding) */
   int32_t rng_impl;     /* FRL_RNG_*: with a threefry layout, bufs.rng_key replaces bufs.noise and the call also produces
                            the rng the reference's sample() returns (bufs.rng_out), for every solver */
+  int32_t layer_norm;   /* 1: the predictor MLP is Dense -> LayerNorm -> act (MLP(layer_norm=True), mlp.py:26-29; flax LayerNorm:
+                           eps 1e-6, fast variance E[x^2] - E[x]^2, scale and bias) — f32 throughput build, forward only */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a
@@ -117,6 +119,9 @@ typedef struct FrlParams {
                                               row order x | time | cond (ddpm.py:92), D' = D or 1      */
   const float* cond_kernel[2]; /* params/cond_embedding/Dense_{0,1}/kernel (cond_in_dim,128), (128,128); cond_embed only */
   const float* cond_bias[2];   /* params/cond_embedding/Dense_{0,1}/bias (128,) */
+  /* params/<predictor>/LayerNorm_i/{scale,bias}, (hidden[i],) each, i = 0..L-1; read when desc.layer_norm = 1 */
+  const float* ln_scale[FRL_MAX_HIDDEN];
+  const float* ln_bias[FRL_MAX_HIDDEN];
 } FrlParams;
 
 /* Noise-schedule tables, each (T+1,) float32 on the device.

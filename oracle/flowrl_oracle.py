@@ -221,10 +221,23 @@ def dense(p, x):
     return x @ p["kernel"] + p["bias"]
 
 
-def mlp_apply(p: Dict, x, n_hidden: int, activation, has_output: bool):
-    """mlp.py:25-33 with layer_norm=False, dropout off (all shipped sampler configs)."""
+def layer_norm(p, x, eps=1e-6):
+    """flax.linen.LayerNorm (flax 0.10.5 defaults: epsilon 1e-6, use_fast_variance: var = max(E[x^2] - E[x]^2, 0),
+    y = (x - mean) * (rsqrt(var + eps) * scale) + bias), over the last axis."""
+    mean = x.mean(axis=-1, keepdims=True)
+    var = np.maximum((x * x).mean(axis=-1, keepdims=True) - mean * mean, 0)
+    mul = (1 / np.sqrt(var + x.dtype.type(eps))) * p["scale"]
+    return (x - mean) * mul + p["bias"]
+
+
+def mlp_apply(p: Dict, x, n_hidden: int, activation, has_output: bool, ln: bool = False):
+    """mlp.py:25-33, dropout off: Dense -> [LayerNorm] -> act per hidden layer (layer_norm is off in all shipped
+    sampler configs; flax names the i-th LayerNorm of the module "LayerNorm_i")."""
     for i in range(n_hidden):
-        x = activation(dense(p[f"Dense_{i}"], x))
+        x = dense(p[f"Dense_{i}"], x)
+        if ln:
+            x = layer_norm(p[f"LayerNorm_{i}"], x)
+        x = activation(x)
     if has_output:
         x = dense(p[f"Dense_{n_hidden}"], x)
     return x
@@ -240,6 +253,7 @@ class BackboneSpec:
     time_dim: int = 64
     cond_hidden: Optional[Sequence[int]] = None     # cond_embedding MLP hidden dims (dacer.py:263-266) or None
     predictor_name: str = "noise_predictor"         # "vel_predictor" for FlowBackbone
+    layer_norm: bool = False                        # MLP(layer_norm=True) predictor (mlp.py:27-28)
     bf16_operands: bool = False                     # emulate the bf16-MFMA variant: predictor Dense operands rounded to
                                                     # bf16 (RNE), products / sums / biases / time slice / activations exact
 
@@ -285,7 +299,7 @@ def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
         inputs = np.concatenate([x, time, condition], axis=-1)
     else:
         inputs = np.concatenate([x, time], axis=-1)
-    return mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, has_output=True)
+    return mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, has_output=True, ln=spec.layer_norm)
 
 
 # --------------------------------------------------------------------------- #
@@ -505,6 +519,10 @@ def make_params(spec: BackboneSpec, cond_dim: int, seed: int, dtype=np.float32, 
         cond_dim = spec.cond_hidden[-1]
     dims = [spec.x_dim + d_time + cond_dim] + list(spec.hidden_dims) + [spec.x_dim]
     p[spec.predictor_name] = {f"Dense_{i}": _dense_params(rng, dims[i], dims[i + 1], dtype) for i in range(len(dims) - 1)}
+    if spec.layer_norm:   # drawn AFTER everything else so that specs without LayerNorm keep their parameter streams
+        for i, h in enumerate(spec.hidden_dims):
+            p[spec.predictor_name][f"LayerNorm_{i}"] = {"scale": (1.0 + 0.2 * rng.standard_normal(h)).astype(dtype),
+                                                        "bias": (0.1 * rng.standard_normal(h)).astype(dtype)}
     return p
 
 

@@ -31,6 +31,7 @@ class Case:
     cond_embed: bool = False       # cond_embedding MLP(128,128): S is then the RAW obs width
     bf16: bool = False             # bf16-MFMA variant (product) / bf16-operand emulation (oracle)
     tile: str = "auto"             # FrlDesc.tile_policy of the product run: auto | throughput | latency
+    ln: bool = False               # MLP(layer_norm=True) predictor: Dense -> LayerNorm -> act (mlp.py:26-29)
 
     @property
     def spec(self):
@@ -38,7 +39,7 @@ class Case:
                                 time_embedding=self.temb, time_dim=64,
                                 cond_hidden=[128, 128] if self.cond_embed else None,
                                 predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor",
-                                bf16_operands=self.bf16)
+                                bf16_operands=self.bf16, layer_norm=self.ln)
 
 
 def make_inputs(c: Case):
@@ -81,7 +82,7 @@ def product_model(c: Case, params, device="cuda"):
         te = fh.PositionalEmbedding(output_dim=64)
     elif c.temb == "learnable_fourier":
         te = fh.LearnableFourierEmbedding(output_dim=64)
-    mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act)
+    mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act, layer_norm=c.ln)
     ce = fh.MLP(hidden_dims=[128, 128], activation=c.act) if c.cond_embed else None
     tparams = fh.tree_from_numpy(params, device)
     inputs = (np.ones((1, c.A)), np.zeros((1, 1)), np.ones((1, c.S)) if c.S > 0 else None)

@@ -246,3 +246,32 @@ def test_against_committed_golden(case):
     print(msg)
     assert H.rel_err(x0, z["x0"]) <= 2e-5 and H.rel_err(xh, z["xt_hist"]) <= 2e-5 and H.rel_err(eh, z["eps_hist"]) <= TOL, msg
     assert H.rms_err(x0, z["x0"]) <= 2e-6, msg
+
+
+def test_layer_norm_backbones():
+    """MLP(layer_norm=True) predictors (mlp.py:26-29: Dense -> LayerNorm -> act): the f32 throughput
+    build normalises every finished pre-activation tile in registers.  The latency build has no LayerNorm pass: a
+    forced LATENCY call is refused loudly, AUTO falls back to the throughput build."""
+    import flowrl_hip as fh
+    cases = [
+        H.Case("ln-ddpm-dql", "ddpm", A=3, S=11, T=5, B=300, ln=True, seed=40),
+        H.Case("ln-ddpm-ddim-silu", "ddpm", A=6, S=17, T=4, B=70, act="silu", solver="ddim", ln=True, seed=41),
+        H.Case("ln-cddpm-particles-wide", "cddpm", A=17, S=128, T=8, B=12 * 8, particles=8, temb="learnable_fourier",
+               schedule="cosine", ln=True, seed=42),
+        H.Case("ln-cnf-512", "cnf", A=8, S=39, T=6, B=100, hidden=(512, 512, 512), act="gelu_tanh", temb=None, clip=False, ln=True, seed=43),
+        H.Case("ln-one-hidden-relu", "ddpm", A=2, S=0, T=6, B=33, hidden=(256,), act="relu", schedule="linear", ln=True, seed=44),
+        H.Case("ln-dpmpp2m", "cddpm", A=3, S=11, T=6, B=64, temb="learnable_fourier", schedule="cosine", solver="dpm++2m", ln=True, seed=45),
+    ]
+    if TILE == "latency":
+        with pytest.raises(fh.FlowRLHipUnsupported):
+            _check(cases[0])
+        return
+    for c in cases:
+        _check(c)
+    # AUTO on a small batch would pick the latency build: with LayerNorm it must take the throughput build instead
+    saved = globals()["TILE"]
+    globals()["TILE"] = "auto"
+    try:
+        _check(cases[0])
+    finally:
+        globals()["TILE"] = saved

@@ -76,8 +76,15 @@ def test_build_desc_and_param_tree_layout():
     q = fh.init_params(flow, 8, 39, seed=1)
     assert tuple(q["vel_predictor"]["Dense_0"]["kernel"].shape) == (8 + 1 + 39, 256) and "MLP_0" not in q
     ln = fh.DDPMBackbone(noise_predictor=fh.MLP(hidden_dims=[256], output_dim=3, activation="mish", layer_norm=True))
+    dl = _sampler.build_desc(ln, kind=0, solver=0, steps=5, n_states=1, particles=1, x_dim=3, cond_dim=0,
+                             clip_sampler=False, x_min=None, x_max=None, want_history=False)
+    assert dl.layer_norm == 1 and d.layer_norm == 0
+    pl = fh.init_params(ln, 3, 0, seed=2)      # flax auto-naming: LayerNorm_i beside Dense_i, scale ones / bias zeros
+    assert set(pl["noise_predictor"]) == {"Dense_0", "Dense_1", "LayerNorm_0"}
+    assert bool((pl["noise_predictor"]["LayerNorm_0"]["scale"] == 1).all()) and not bool(pl["noise_predictor"]["LayerNorm_0"]["bias"].any())
+    drop = fh.DDPMBackbone(noise_predictor=fh.MLP(hidden_dims=[256], output_dim=3, activation="mish", dropout=0.1))
     with pytest.raises(_lib.FlowRLHipUnsupported):
-        _sampler.build_desc(ln, kind=0, solver=0, steps=5, n_states=1, particles=1, x_dim=3, cond_dim=0,
+        _sampler.build_desc(drop, kind=0, solver=0, steps=5, n_states=1, particles=1, x_dim=3, cond_dim=0,
                             clip_sampler=False, x_min=None, x_max=None, want_history=False)
 
 

@@ -344,3 +344,29 @@ def test_critic_select_known_answers():
     np.testing.assert_array_equal(chosen, act[np.arange(B), idx])
     g = np.zeros((B, N)); g[:, 3] = 1e6                                       # overwhelming Gumbel noise picks candidate 3
     assert (orc.select_best(p, obs, act, 1, "relu", temperature=1.0, gumbel=g)[1] == 3).all()
+
+
+def test_layer_norm_known_answers():
+    """flax.linen.LayerNorm restated (oracle layer_norm / mlp_apply(ln=True), mlp.py:26-29): closed forms and an
+    independent torch evaluation (torch's layer_norm uses the two-pass variance; float64 makes the forms agree)."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((5, 256))
+    p = {"scale": 1.0 + 0.2 * rng.standard_normal(256), "bias": 0.1 * rng.standard_normal(256)}
+    y = orc.layer_norm(p, x)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (256,), torch.from_numpy(p["scale"]), torch.from_numpy(p["bias"]), eps=1e-6).numpy()
+    assert np.abs(y - ref).max() < 1e-12
+    # identity parameters: zero mean, unit variance (up to eps); constant rows map to the bias exactly
+    one = {"scale": np.ones(256), "bias": np.zeros(256)}
+    z = orc.layer_norm(one, x)
+    assert np.abs(z.mean(-1)).max() < 1e-12 and np.abs(z.var(-1) - 1).max() < 1e-5
+    c = orc.layer_norm(p, np.full((2, 256), 3.25))
+    assert np.array_equal(c, np.broadcast_to(p["bias"], (2, 256)))
+    # a LayerNorm backbone differs from the plain one and uses the LayerNorm_i leaves
+    spec = orc.BackboneSpec(hidden_dims=[256, 256], x_dim=3, layer_norm=True)
+    prm = orc.make_params(spec, 11, seed=1, dtype=np.float64)
+    assert set(prm["noise_predictor"]) == {"Dense_0", "Dense_1", "Dense_2", "LayerNorm_0", "LayerNorm_1"}
+    xx, t, cd = rng.standard_normal((4, 3)), np.full((4, 1), 2.0), rng.standard_normal((4, 11))
+    a = orc.backbone_apply(spec, prm, xx, t, cd)
+    b = orc.backbone_apply(orc.BackboneSpec(hidden_dims=[256, 256], x_dim=3), prm, xx, t, cd)
+    assert a.shape == (4, 3) and np.abs(a - b).max() > 1e-3
