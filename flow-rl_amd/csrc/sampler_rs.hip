@@ -37,7 +37,7 @@
 
 namespace frl {
 
-template <int TR, int H, int ACT, int NRX, int CKMAX, bool EXT>
+template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_rs_kernel(const KArgs a) {
   typedef Geo<TR> G;
@@ -69,8 +69,8 @@ frl_sampler_rs_kernel(const KArgs a) {
   }
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
   for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
-  float* s_ln = s_coef + a.NE * COEF_STRIDE;          // EXT, LayerNorm backbones only: [L][2][H] scale | bias rows
-  if constexpr (EXT) {
+  float* s_ln = s_coef + a.NE * COEF_STRIDE;          // EXT 2, LayerNorm backbones only: [L][2][H] scale | bias rows
+  if constexpr (EXT >= 2) {
     if (a.ws_ln != nullptr)
       for (int idx = tid; idx < a.L * 2 * H; idx += blockDim.x) s_ln[idx] = a.ws_ln[idx];
   }
@@ -190,7 +190,7 @@ frl_sampler_rs_kernel(const KArgs a) {
 
     for (int j = 0; j < a.NE; ++j) {   // one iteration per network evaluation (= per sampler step, except dpm2: two)
       float zr[NRX];
-      if constexpr (EXT) {
+      if constexpr (EXT >= 2) {
         // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai] (frl_rng.h), drawn while no accumulator is live
         if (a.rng_impl != FRL_RNG_NONE) {
           const bool used = s_coef[j * COEF_STRIDE + 5] != 0.0f;   // c5 = 0: the last iteration multiplies its draw by 0 (ddpm.py:206)
@@ -233,14 +233,14 @@ frl_sampler_rs_kernel(const KArgs a) {
       });
 
       // noise for this step and the first Dense_L operands: issued now, consumed after the hidden layers
-      if (!EXT || a.rng_impl == FRL_RNG_NONE) {
+      if (EXT < 2 || a.rng_impl == FRL_RNG_NONE) {
         sfor<NRX>([&](auto RI) {
           constexpr int r = decltype(RI)::value;
           const int ai = G::rowr(r) + 4 * ls;
           zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         });
       }
-      if constexpr (EXT) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
+      if constexpr (EXT >= 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
       constexpr int NLD = NK / 4;    // Dense_L: 16-byte loads, load q covers k-steps 4q .. 4q+3
       f32x4 rl[RINGL];
       sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
@@ -277,7 +277,7 @@ frl_sampler_rs_kernel(const KArgs a) {
           bop = bn1; bn1 = bn2;
         });
         sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; P[b] = Q[b]; });
-        if constexpr (EXT) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
+        if constexpr (EXT >= 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
       }
 
       // next step's (or next tile's) first Dense_0 operands: in flight under Dense_L and the epilogue
@@ -380,7 +380,7 @@ static int device_cus_rs() {
   return cus[dev];
 }
 
-template <int TR, int H, int ACT, int NRX, int CKMAX, bool EXT>
+template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
 static int launch_inst_v(const KArgs& a, hipStream_t stream) {
   auto kern = frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX, EXT>;
   const int ncu = device_cus_rs();
@@ -407,13 +407,15 @@ static int launch_inst_v(const KArgs& a, hipStream_t stream) {
   return FRL_OK;
 }
 
-// Two builds of every geometry: the plain one (ddpm / ddim / Euler, condition contracted in the kernel) keeps the
-// register budget of the tuned hot loop; EXT adds what the rarer paths need (dpm2 / dpm++2m carry registers, plain
-// evaluation for critics, per-state hoisted condition rows).
+// Three builds of every geometry: the plain one (ddpm / ddim / Euler, condition contracted in the kernel) keeps the
+// register budget of the tuned hot loop; EXT 1 adds what the rarer paths need (dpm2 / dpm++2m carry registers, plain
+// evaluation for critics, per-state hoisted condition rows); EXT 2 adds the in-kernel threefry draws and the LayerNorm
+// pass, so that the hoisted cfg4 path does not carry their code either.
 template <int TR, int H, int ACT, int NRX, int CKMAX>
 static int launch_inst(const KArgs& a, hipStream_t stream) {
-  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, true>(a, stream);
-  return launch_inst_v<TR, H, ACT, NRX, CKMAX, false>(a, stream);
+  if (a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 2>(a, stream);
+  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 1>(a, stream);
+  return launch_inst_v<TR, H, ACT, NRX, CKMAX, 0>(a, stream);
 }
 
 template <int ACT>
