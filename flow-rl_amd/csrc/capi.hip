@@ -544,10 +544,14 @@ int frl_random_split(const uint32_t* key, int32_t impl, int32_t num, uint32_t* o
   return launch_random_split(key, impl, num, out, (hipStream_t)hip_stream);
 }
 int frl_random_normal(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream) {
-  return launch_random_fill(key, impl, n, out, true, (hipStream_t)hip_stream);
+  return launch_random_fill(key, impl, n, out, 1, (hipStream_t)hip_stream);
 }
 int frl_random_bits(const uint32_t* key, int32_t impl, int64_t n, uint32_t* out, void* hip_stream) {
-  return launch_random_fill(key, impl, n, out, false, (hipStream_t)hip_stream);
+  return launch_random_fill(key, impl, n, out, 0, (hipStream_t)hip_stream);
+}
+
+int frl_random_gumbel(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream) {
+  return launch_random_fill(key, impl, n, out, 2, (hipStream_t)hip_stream);
 }
 
 int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream) {

@@ -259,7 +259,7 @@ struct TBArgs {
 int launch_time_bwd(const TBArgs& a, hipStream_t stream);
 int launch_rng_chain(const uint32_t* key_in, int impl, int mode, int T, uint32_t* keys, uint32_t* rng_out, hipStream_t stream);
 int launch_random_split(const uint32_t* key, int impl, int num, uint32_t* out, hipStream_t stream);
-int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, bool normal, hipStream_t stream);
+int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, int kind, hipStream_t stream);   // 0 bits, 1 normal, 2 gumbel
 
 int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
 int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, hipStream_t stream);

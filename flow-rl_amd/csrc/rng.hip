@@ -61,12 +61,20 @@ __global__ void frl_random_split_kernel(const uint32_t* __restrict__ key, int im
   out[2 * i] = o0; out[2 * i + 1] = o1;
 }
 
-template <bool NORMAL>
+// KIND 0: raw bits; 1: normal; 2: gumbel = -log(-log(u)), u = uniform(minval = FLT_MIN, maxval = 1): the mantissa-trick
+// float f in [0, 1) times (1 - tiny) (= 1 in f32) plus tiny, floored at tiny, i.e. f, or tiny where f = 0
+template <int KIND>
 __global__ void frl_random_fill_kernel(const uint32_t* __restrict__ key, int impl, unsigned long long n, void* __restrict__ out) {
   const uint32_t k0 = key[0], k1 = key[1];
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
     const uint32_t b = rng_bits(k0, k1, impl, n, i);
-    if (NORMAL) ((float*)out)[i] = rng_bits_to_normal(b); else ((uint32_t*)out)[i] = b;
+    if (KIND == 1) ((float*)out)[i] = rng_bits_to_normal(b);
+    else if (KIND == 2) {
+      const float tiny = 1.17549435e-38f;
+      const float f = __uint_as_float((b >> 9) | 0x3F800000u) - 1.0f;
+      const float u = fmaxf(tiny, f * 1.0f + tiny);
+      ((float*)out)[i] = -logf(-logf(u));
+    } else ((uint32_t*)out)[i] = b;
   }
 }
 
@@ -86,7 +94,7 @@ int launch_random_split(const uint32_t* key, int impl, int num, uint32_t* out, h
   return FRL_OK;
 }
 
-int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, bool normal, hipStream_t stream) {
+int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, int kind, hipStream_t stream) {
   int rc = check_impl(impl);
   if (rc != FRL_OK) return rc;
   if (key == nullptr || (out == nullptr && n > 0) || n < 0) { set_error("random fill: bad arguments"); return FRL_EINVAL; }
@@ -94,8 +102,9 @@ int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, bo
   if (n == 0) return FRL_OK;
   const long long want = (n + 255) / 256, cap = 16ll * device_cus();
   const int grid = (int)(want < cap ? want : cap);
-  if (normal) hipLaunchKernelGGL(frl_random_fill_kernel<true>, dim3(grid), dim3(256), 0, stream, key, impl, (unsigned long long)n, out);
-  else hipLaunchKernelGGL(frl_random_fill_kernel<false>, dim3(grid), dim3(256), 0, stream, key, impl, (unsigned long long)n, out);
+  if (kind == 1) hipLaunchKernelGGL(frl_random_fill_kernel<1>, dim3(grid), dim3(256), 0, stream, key, impl, (unsigned long long)n, out);
+  else if (kind == 2) hipLaunchKernelGGL(frl_random_fill_kernel<2>, dim3(grid), dim3(256), 0, stream, key, impl, (unsigned long long)n, out);
+  else hipLaunchKernelGGL(frl_random_fill_kernel<0>, dim3(grid), dim3(256), 0, stream, key, impl, (unsigned long long)n, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("random fill launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;

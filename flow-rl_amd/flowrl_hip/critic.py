@@ -125,14 +125,30 @@ def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor],
 
 def sample_and_select(model, critic: Ensemblize, critic_params: Dict, rng, obs: torch.Tensor, training: bool, num_samples: int,
                       solver: str, temperature: Optional[float], *, xT: Optional[torch.Tensor] = None,
-                      noise: Optional[torch.Tensor] = None, gumbel: Optional[torch.Tensor] = None, compute_dtype: str = "f32"):
+                      noise: Optional[torch.Tensor] = None, gumbel: Optional[torch.Tensor] = None, compute_dtype: str = "f32",
+                      rng_impl: Optional[str] = None):
     """jit_sample_and_select (dql.py:130-162): num_samples chains per observation, then the critic picks one.
-    ``xT`` (B, N, A) / ``noise`` / ``gumbel`` are the reference's random draws, supplied by the caller."""
+    With a threefry key as ``rng`` (flowrl_hip.random.PRNGKey) the call is the reference's rng-in / rng-out protocol,
+    all on the GPU: ``rng, xT_rng = split(rng)``; ``xT = normal(xT_rng, (B, N, A))``; the sampler draws its noise
+    in-kernel and advances the rng; ``rng, select_rng = split(rng)`` and Gumbel-max over ``gumbel(select_rng, (B, N))``
+    when temperature > 0.  Otherwise ``xT`` (B, N, A) / ``noise`` / ``gumbel`` are the reference's draws supplied by the
+    caller (torch draws when absent) and ``rng`` is returned unchanged."""
+    from . import random as fr
     B = obs.shape[0]
-    if xT is None:
+    keyed = fr.is_key(rng)
+    if keyed:
+        rng, xT_rng = fr.split(fr.as_key(rng, obs.device), 2, rng_impl)                                  # dql.py:142
+        if xT is None:
+            xT = fr.normal(xT_rng, (B, num_samples, model.x_dim), rng_impl)                              # dql.py:146
+    elif xT is None:
         xT = torch.randn((B, num_samples, model.x_dim), dtype=torch.float32, device=obs.device)
-    rng, actions, _ = model.sample(rng, xT, obs, training, solver, noise=noise, particles=num_samples, compute_dtype=compute_dtype)
+    kw = dict(rng_impl=rng_impl) if keyed else {}
+    rng, actions, _ = model.sample(rng, xT, obs, training, solver, noise=noise, particles=num_samples, compute_dtype=compute_dtype, **kw)
     if temperature is None:
         return rng, actions[:, 0]                                           # dql.py:148-149
+    if keyed and temperature > 0.0:
+        rng, select_rng = fr.split(rng, 2, rng_impl)                                                     # dql.py:159
+        if gumbel is None:
+            gumbel = fr.gumbel(select_rng, (B, num_samples), rng_impl)                                   # categorical, dql.py:160
     best, _, _ = critic_select(critic, critic_params, obs, actions, num_samples, temperature=temperature, gumbel=gumbel, want_q=False)
     return rng, best

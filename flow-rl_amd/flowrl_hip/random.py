@@ -78,3 +78,8 @@ def normal(key: torch.Tensor, shape, impl: str = None) -> torch.Tensor:
 def bits(key: torch.Tensor, shape, impl: str = None) -> torch.Tensor:
     """jax.random.bits(key, shape) (uint32)."""
     return _fill("frl_random_bits", key, shape, torch.uint32, impl)
+
+
+def gumbel(key: torch.Tensor, shape, impl: str = None) -> torch.Tensor:
+    """jax.random.gumbel(key, shape) (float32): the noise jax.random.categorical adds to its logits (dql.py:159-160)."""
+    return _fill("frl_random_gumbel", key, shape, torch.float32, impl)

@@ -273,10 +273,13 @@ const char* frl_last_error(void);
  * calling sample): keys are device (2,) uint32, impl is FRL_RNG_THREEFRY_*.
  *   frl_random_split   out (num, 2) uint32 = jax.random.split(key, num)
  *   frl_random_normal  out (n,) f32        = jax.random.normal(key, shape) flattened, n = prod(shape)
- *   frl_random_bits    out (n,) uint32     = jax.random.bits(key, shape) flattened                               */
+ *   frl_random_bits    out (n,) uint32     = jax.random.bits(key, shape) flattened
+ *   frl_random_gumbel  out (n,) f32        = jax.random.gumbel(key, shape) flattened: -log(-log(uniform(tiny, 1))), the
+ *                                            noise of jax.random.categorical (dql.py:159-160) -> FrlSelectBufs.gumbel  */
 int frl_random_split(const uint32_t* key, int32_t impl, int32_t num, uint32_t* out, void* hip_stream);
 int frl_random_normal(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream);
 int frl_random_bits(const uint32_t* key, int32_t impl, int64_t n, uint32_t* out, void* hip_stream);
+int frl_random_gumbel(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream);
 
 int frl_abi_version(void);
 

@@ -112,6 +112,13 @@ def normal(key, shape, impl="partitionable"):
     return normal_from_bits(random_bits(key, shape, impl))
 
 
+def gumbel(key, shape, impl="partitionable"):
+    """jax.random.gumbel: -log(-log(uniform(key, shape, minval=finfo.tiny, maxval=1))) in float32."""
+    tiny = np.finfo(np.float32).tiny
+    u = uniform_from_bits(random_bits(key, shape, impl), tiny, np.float32(1.0))
+    return (-np.log(-np.log(u))).astype(np.float32)
+
+
 def sampler_key_chain(kind, solver, steps, key, impl="partitionable"):
     """The split sequence inside the reference's scans.  Returns (noise_keys (n_steps, 2) uint32 — the key_ of every
     loop iteration, zeros where the solver draws none — and the rng the sampler returns)."""

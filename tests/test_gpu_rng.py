@@ -166,3 +166,58 @@ def test_empty_batch_advances_rng():
     rng, x0, _ = model.sample(_t(key), _t(xT[:0]), _t(cond[:0]), False, "ddpm")
     torch.cuda.synchronize()
     assert x0.shape == (0, case.A) and np.array_equal(rng.cpu().numpy(), rng_ref)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_gumbel(impl):
+    import flowrl_hip.random as fr
+    k = tf.prng_key(21)
+    for shape in ((1,), (40, 8), (100001,)):
+        got = fr.gumbel(_key(21), shape, impl).cpu().numpy()
+        ref = tf.gumbel(k, shape, impl)
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        # -log(-log(u)): two ocml logs against numpy's; near u -> 1 the outer log amplifies the inner one's ulp
+        err = np.abs(got.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+        assert err.max() <= 2e-6, (shape, err.max())
+    g = tf.gumbel(k, (400000,), impl)
+    assert abs(float(g.mean()) - 0.5772) < 5e-3 and abs(float(g.var()) - np.pi ** 2 / 6) < 2e-2
+
+
+@pytest.mark.parametrize("temperature", [None, 0.0, 0.7])
+def test_sample_and_select_rng_in_rng_out(temperature):
+    """jit_sample_and_select (dql.py:130-162) with a threefry key: split -> xT -> sampler (in-kernel noise) -> critic ->
+    [split -> categorical], against the oracle run on the oracle's draws for the same key; the returned rng bit-exact."""
+    import torch
+    import flowrl_hip as fh
+    import flowrl_oracle as orc
+    Bs, N, A, S = 40, 8, 3, 11
+    c = H.Case("sel", "ddpm", A=A, S=S, T=5, B=Bs * N, particles=N, seed=11)
+    params, _, cond, _ = H.make_inputs(c)
+    cp = orc.make_critic_params(S, A, (256, 256), 2, 12)
+    key = tf.prng_key(77)
+    # the reference's sequence on the CPU
+    rng, xT_rng = tf.split(key, 2)
+    xT = tf.normal(xT_rng, (Bs, N, A))
+    noise, rng = tf.sampler_noise("ddpm", "ddpm", c.T, rng, (Bs, N, A))
+    x0_ref, _, _ = H.oracle_run(c, params, xT.reshape(Bs * N, A), cond, noise.reshape(c.T, Bs * N, A), dtype=np.float64)
+    acts = x0_ref.reshape(Bs, N, A)
+    if temperature is None:
+        want, clear = acts[:, 0], np.ones(Bs, bool)
+    else:
+        g = None
+        if temperature > 0.0:
+            rng, sel = tf.split(rng, 2)
+            g = tf.gumbel(sel, (Bs, N)).astype(np.float64)
+        _, idx_ref, q_ref = orc.select_best(orc.cast_tree(cp, np.float64), cond.astype(np.float64), acts, 2, "mish",
+                                            temperature=temperature or 0.0, gumbel=g)
+        score = q_ref / (1e-6 + temperature) + g if g is not None else q_ref
+        srt = np.sort(score, axis=-1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-3
+        want = acts[np.arange(Bs), idx_ref]
+        assert clear.sum() >= 30
+    model = H.product_model(c, params)
+    critic = fh.Ensemblize(base=fh.ScalarCritic(backbone=fh.MLP(hidden_dims=[256, 256], activation="mish")), ensemble_size=2)
+    rng_out, best = fh.sample_and_select(model, critic, fh.tree_from_numpy(cp, "cuda"), _t(key), _t(cond), False, N, "ddpm", temperature)
+    torch.cuda.synchronize()
+    assert np.array_equal(rng_out.cpu().numpy(), rng)
+    np.testing.assert_allclose(best.cpu().numpy()[clear], want[clear], atol=1e-4)
