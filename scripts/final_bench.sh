@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-end measurement set: smoke, every BASELINE config once (kernel timing + roofline), and the profile of the default run.
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/final
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.log 2>&1 || exit 2
+timeout -k 10 300 python bench.py > gpurun_out/final/cfg2.json 2> gpurun_out/final/cfg2.err || exit 3
+timeout -k 10 200 python bench.py --workload cfg1 --no-cpu-baseline > gpurun_out/final/cfg1.json 2>/dev/null || exit 4
+timeout -k 10 300 python bench.py --workload cfg3 --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/final/cfg3.json 2>/dev/null || exit 5
+timeout -k 10 300 python bench.py --workload cfg4 --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4.json 2>/dev/null || exit 6
+timeout -k 10 200 python bench.py --workload cfg5 --no-cpu-baseline > gpurun_out/final/cfg5_f32.json 2>/dev/null || exit 7
+timeout -k 10 200 python bench.py --workload cfg5 --dtype bf16 --no-cpu-baseline > gpurun_out/final/cfg5_bf16.json 2>/dev/null || exit 8
+timeout -k 10 200 python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/final/cfg2_bf16.json 2>/dev/null || exit 9
+scripts/prof.sh final > gpurun_out/final/prof.log 2>&1 || exit 10
+echo done
