@@ -11,7 +11,8 @@
 //          tb[j] = bias_0 + tfeat[j] @ kernel_0[A : A + D', :]
 //  * zero-padded, MFMA-friendly images of the two edge layers (Dense_0's x / cond rows, Dense_L).
 //
-// One workgroup; O(T * (D^2 + D*H)) work — microseconds.  Transcendentals here go through double
+// Workgroup e < NE runs the coefficient row and the time branch of network evaluation e (a chain of small dependent
+// stages); the other workgroups pack the edge-layer images (independent grid-stride copies).  O(T * (D^2 + D*H)) work — microseconds.  Transcendentals here go through double
 // precision so that each f32 op of the reference is reproduced correctly rounded.
 #include "frl_internal.h"
 
@@ -22,6 +23,52 @@ __device__ __forceinline__ float mish_exact(float x) {
   double xd = (double)x;
   double sp = (xd > 30.0) ? xd : log1p(exp(xd));
   return (float)(xd * tanh(sp));
+}
+
+// Zero-padded, MFMA-friendly images of the two edge layers: independent element-wise copies, strided over `nt` threads.
+__device__ __forceinline__ void pack_edge_layers(const PArgs& a, int tid, int nt) {
+  const Plan& pl = a.plan;
+  const int H = pl.H, A = pl.A, C = pl.C, AO = pl.AO;
+  float* ws = a.ws;
+  float* w0p = ws + pl.off_w0p;
+  float* wlp = ws + pl.off_wlp;
+  float* wlq = ws + pl.off_wlq;
+  float* blp = ws + pl.off_blp;
+  const float* W0 = a.p.kernel[0];
+  // ---- packed layer-0 image: rows [0, XR) = x rows (zero beyond A), then cond rows (zero beyond C) --
+  const int w0_rows = (int)pl.w0p_rows;
+  for (int idx = tid; idx < w0_rows * H; idx += nt) {
+    const int r = idx / H, f = idx - r * H;
+    float v = 0.0f;
+    if (r < pl.XR) {
+      if (r < A) v = W0[(size_t)(pl.x_row0 + r) * H + f];
+    } else {
+      const int k = r - pl.XR;
+      if (k < C) v = W0[(size_t)(pl.c_row0 + k) * H + f];
+    }
+    w0p[idx] = v;
+  }
+  // ---- last layer padded to LAST_PAD output columns ---------------------------------------------------
+  const int HL = pl.H;   // width of the last hidden layer
+  const float* WL = a.p.kernel[pl.L];
+  for (int idx = tid; idx < HL * LAST_PAD; idx += nt) {
+    const int k = idx / LAST_PAD, i = idx - k * LAST_PAD;
+    wlp[idx] = (i < AO) ? WL[(size_t)k * AO + i] : 0.0f;
+  }
+  for (int i = tid; i < LAST_PAD; i += nt) blp[i] = (i < AO) ? a.p.bias[pl.L][i] : 0.0f;
+  // ---- last layer, per-lane packed: load q (16 B per lane) = A operands of k-steps 4q..4q+3, k = block*NR + r,
+  //      lane (i = lane % TR, s = lane / TR) contracts feature GW*g + j + 4*(ROWR(r) + 4 s), block = 4 g + j ----
+  {
+    const int TR = pl.TR, NR = pl.NR, GW = 4 * TR;
+    for (int idx = tid; idx < HL * 64; idx += nt) {
+      const int q = idx >> 8, lane = (idx >> 2) & 63, e = idx & 3;
+      const int k = 4 * q + e, blk = k / NR, r = k - blk * NR;
+      const int rowr = (TR == 32) ? ((r & 3) + 8 * (r >> 2)) : ((r & 3) + 16 * (r >> 2));
+      const int i = lane % TR, sl = lane / TR;
+      const int kf = GW * (blk >> 2) + (blk & 3) + 4 * (rowr + 4 * sl);
+      wlq[idx] = (i < AO && kf < HL) ? WL[(size_t)kf * AO + i] : 0.0f;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
@@ -41,9 +88,17 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   float* h2 = h1 + (size_t)pl.NE * (D > 0 ? D : 1);
   __shared__ float tvals[256];      // time input of network evaluation e (NE <= 256 checked on host)
 
-  // ---- coefficients + time values, one row per network evaluation -----------------------------------
   const int NE = pl.NE;
-  for (int e = tid; e < NE; e += nt) {
+  const float* W0 = a.p.kernel[0];
+  const float* b0 = a.p.bias[0];
+  if ((int)blockIdx.x >= NE) {
+    pack_edge_layers(a, (int)(blockIdx.x - NE) * nt + tid, (int)(gridDim.x - NE) * nt);
+    return;
+  }
+  // workgroup e < NE owns network evaluation row e: its coefficients, its time features, its row of tb
+  const int e0 = blockIdx.x, e1 = e0 + 1;
+  // ---- coefficients + time values, one row per network evaluation -----------------------------------
+  for (int e = e0 + tid; e < e1; e += nt) {
     float c[COEF_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
     float tv;
     const int j = (pl.mode == MODE_CDDPM_DPM2) ? e >> 1 : e;     // loop iteration of the reference's scan
@@ -116,19 +171,16 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   }
   __syncthreads();
 
-  const float* W0 = a.p.kernel[0];
-  const float* b0 = a.p.bias[0];
-
   if (a.time_embed == FRL_TEMB_NONE) {
     // raw scalar time is input column A of Dense_0 (cnf.py:38-41)
-    for (int idx = tid; idx < NE * H; idx += nt) {
+    for (int idx = e0 * H + tid; idx < e1 * H; idx += nt) {
       const int j = idx / H, f = idx - j * H;
       tb[idx] = (Dp == 0) ? b0[f] : fmaf(tvals[j], W0[(size_t)A * H + f], b0[f]);
     }
   } else {
     const int half = D / 2;
     // ---- embedding ------------------------------------------------------------------------------
-    for (int idx = tid; idx < NE * D; idx += nt) {
+    for (int idx = e0 * D + tid; idx < e1 * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       const int dd = (d < half) ? d : d - half;
       float arg;
@@ -146,7 +198,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
     __syncthreads();
     // ---- MLP_0/Dense_0 + mish ---------------------------------------------------------------------
-    for (int idx = tid; idx < NE * D; idx += nt) {
+    for (int idx = e0 * D + tid; idx < e1 * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       float acc = 0.0f;
       for (int k = 0; k < D; ++k) acc = fmaf(temb[j * D + k], a.p.tmlp_kernel[0][(size_t)k * D + d], acc);
@@ -154,7 +206,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
     __syncthreads();
     // ---- MLP_0/Dense_1 + mish ---------------------------------------------------------------------
-    for (int idx = tid; idx < NE * D; idx += nt) {
+    for (int idx = e0 * D + tid; idx < e1 * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       float acc = 0.0f;
       for (int k = 0; k < D; ++k) acc = fmaf(h1[j * D + k], a.p.tmlp_kernel[1][(size_t)k * D + d], acc);
@@ -162,7 +214,7 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
     __syncthreads();
     // ---- time slice of predictor Dense_0 -> bias table --------------------------------------------
-    for (int idx = tid; idx < NE * H; idx += nt) {
+    for (int idx = e0 * H + tid; idx < e1 * H; idx += nt) {
       const int j = idx / H, f = idx - j * H;
       float acc = 0.0f;
       for (int k = 0; k < D; ++k) acc = fmaf(h2[j * D + k], W0[(size_t)(A + k) * H + f], acc);
@@ -170,47 +222,13 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
     }
   }
 
-  // ---- packed layer-0 image: rows [0, XR) = x rows (zero beyond A), then cond rows (zero beyond C) --
-  const int w0_rows = (int)pl.w0p_rows;
-  for (int idx = tid; idx < w0_rows * H; idx += nt) {
-    const int r = idx / H, f = idx - r * H;
-    float v = 0.0f;
-    if (r < pl.XR) {
-      if (r < A) v = W0[(size_t)(pl.x_row0 + r) * H + f];
-    } else {
-      const int k = r - pl.XR;
-      if (k < C) v = W0[(size_t)(pl.c_row0 + k) * H + f];
-    }
-    w0p[idx] = v;
-  }
-  // ---- last layer padded to LAST_PAD output columns ---------------------------------------------------
-  const int HL = pl.H;   // width of the last hidden layer
-  const float* WL = a.p.kernel[pl.L];
-  for (int idx = tid; idx < HL * LAST_PAD; idx += nt) {
-    const int k = idx / LAST_PAD, i = idx - k * LAST_PAD;
-    wlp[idx] = (i < AO) ? WL[(size_t)k * AO + i] : 0.0f;
-  }
-  for (int i = tid; i < LAST_PAD; i += nt) blp[i] = (i < AO) ? a.p.bias[pl.L][i] : 0.0f;
-  // ---- last layer, per-lane packed: load q (16 B per lane) = A operands of k-steps 4q..4q+3, k = block*NR + r,
-  //      lane (i = lane % TR, s = lane / TR) contracts feature GW*g + j + 4*(ROWR(r) + 4 s), block = 4 g + j ----
-  {
-    const int TR = pl.TR, NR = pl.NR, GW = 4 * TR;
-    for (int idx = tid; idx < HL * 64; idx += nt) {
-      const int q = idx >> 8, lane = (idx >> 2) & 63, e = idx & 3;
-      const int k = 4 * q + e, blk = k / NR, r = k - blk * NR;
-      const int rowr = (TR == 32) ? ((r & 3) + 8 * (r >> 2)) : ((r & 3) + 16 * (r >> 2));
-      const int i = lane % TR, sl = lane / TR;
-      const int kf = GW * (blk >> 2) + (blk & 3) + 4 * (rowr + 4 * sl);
-      wlq[idx] = (i < AO && kf < HL) ? WL[(size_t)kf * AO + i] : 0.0f;
-    }
-  }
 }
 
 int launch_prepare(const PArgs& a, hipStream_t stream) {
   const int Dm = a.plan.D > 0 ? a.plan.D : 1;
   const size_t shbytes = (size_t)3 * a.plan.NE * Dm * sizeof(float);
   if (shbytes > 60000) { set_error("prepare: T*time_dim too large (%zu B of LDS)", shbytes); return FRL_EUNSUPPORTED; }
-  hipLaunchKernelGGL(frl_prepare_kernel, dim3(1), dim3(256), shbytes, stream, a);
+  hipLaunchKernelGGL(frl_prepare_kernel, dim3(a.plan.NE + 32), dim3(256), shbytes, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
