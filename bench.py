@@ -252,7 +252,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (H = 256 workloads)")
-    ap.add_argument("--tile-policy", default="auto", choices=["auto", "throughput", "latency"],
+    ap.add_argument("--tile-policy", default="auto", choices=["auto", "throughput", "latency", "latency32", "latency16"],
                     help="f32 forward kernel build (FrlDesc.tile_policy); auto = latency build for small batches")
     ap.add_argument("--cache-prepare", action="store_true",
                     help="let the host wrapper reuse the prepared tables / packed weights across calls (acting between two "
@@ -340,7 +340,7 @@ def main():
     if rank == 0:
         k_ms, flops_alg, flops_exec = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        lat = args.tile_policy == "latency" or (args.tile_policy == "auto" and -(-((B + 31) // 32) // ncu) <= 3 * -(-((B + 31) // 32) // (4 * ncu)))
+        lat = args.tile_policy.startswith("latency") or (args.tile_policy == "auto" and (B + 15) // 16 <= ncu) or (args.tile_policy == "auto" and -(-((B + 31) // 32) // ncu) <= 3 * -(-((B + 31) // 32) // (4 * ncu)))
         kname = "frl_sampler_lat_kernel" if (lat and args.dtype == "f32") else "frl_sampler_rs_kernel"
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit

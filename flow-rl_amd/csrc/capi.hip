@@ -21,26 +21,31 @@ void set_error(const char* fmt, ...) {
 // f32 network kernel dispatch: latency build for small batches, throughput build otherwise
 static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStream_t stream) {
   const long long ntiles = (a.B + 31) / 32;
+  const long long cus = device_cus();
   bool lat = false;
-  if (tile_policy == FRL_TILE_LATENCY) {
-    if (!sampler_lat_supports(a)) { set_error("tile_policy LATENCY: this configuration has no latency build (H %d, x_dim %d, operand cond rows %d, x rows %d, evaluations %d, LDS %zu bytes)", a.H, a.A, a.C, a.XR, a.NE, lat_lds_bytes(a.NE, a.L, a.H, false)); return FRL_EUNSUPPORTED; }
+  int tile_rows = 0;   // latency build: 0 = its own choice between 16- and 32-chain tiles
+  if (tile_policy == FRL_TILE_LATENCY || tile_policy == FRL_TILE_LATENCY_32 || tile_policy == FRL_TILE_LATENCY_16) {
+    tile_rows = tile_policy == FRL_TILE_LATENCY_32 ? 32 : tile_policy == FRL_TILE_LATENCY_16 ? 16 : 0;
+    const bool ok = tile_rows == 32 ? sampler_lat_supports(a) : tile_rows == 16 ? sampler_lat16_supports(a)
+                                    : (sampler_lat_supports(a) || sampler_lat16_supports(a));
+    if (!ok) { set_error("tile_policy %d: this configuration has no such latency build (H %d, x_dim %d, operand cond rows %d, x rows %d, evaluations %d, LDS %zu bytes)", tile_policy, a.H, a.A, a.C, a.XR, a.NE, lat_lds_bytes(a.NE, a.L, a.H, false)); return FRL_EUNSUPPORTED; }
     lat = true;
-  } else if (tile_policy == FRL_TILE_AUTO) {
+  } else if (tile_policy == FRL_TILE_AUTO && a.ws_ln == nullptr) {
     // Measured on MI355X (cfg2 geometry, scripts/sweep_tile.sh): one round of latency-build tiles (one per CU) takes
     // 0.12 ms, one round of throughput-build tiles (four per CU) 0.38 ms.  The latency build wins whenever its
-    // rounds cost less, i.e. for small batches and for batches whose last throughput round would be mostly empty.
-    const long long cus = device_cus();
+    // rounds cost less, i.e. for small batches and for batches whose last throughput round would be mostly empty;
+    // below 16 chains per CU its 16-chain tiles halve the round again.
     const long long r_lat = (ntiles + cus - 1) / cus, r_thr = (ntiles + 4 * cus - 1) / (4 * cus);
-    lat = r_lat <= 3 * r_thr && sampler_lat_supports(a) && a.ws_ln == nullptr;
+    lat = (sampler_lat16_supports(a) && (a.B + 15) / 16 <= cus) || (r_lat <= 3 * r_thr && sampler_lat_supports(a));
   }
   if (lat) {
     switch (act) {
-      case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, stream);
-      case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, stream);
-      case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, stream);
-      case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, stream);
-      case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, stream);
-      default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, stream);
+      case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, tile_rows, stream);
+      case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, tile_rows, stream);
+      case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, tile_rows, stream);
+      case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, tile_rows, stream);
+      case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, tile_rows, stream);
+      default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, tile_rows, stream);
     }
   }
   switch (act) {
@@ -81,11 +86,11 @@ static int validate_desc(const FrlDesc* d) {
   if (d->act < FRL_ACT_MISH || d->act > FRL_ACT_ELU) { set_error("act %d invalid", d->act); return FRL_EINVAL; }
   if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
   if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
-  if (d->tile_policy < FRL_TILE_AUTO || d->tile_policy > FRL_TILE_LATENCY) { set_error("tile_policy %d invalid", d->tile_policy); return FRL_EINVAL; }
+  if (d->tile_policy < FRL_TILE_AUTO || d->tile_policy > FRL_TILE_LATENCY_16) { set_error("tile_policy %d invalid", d->tile_policy); return FRL_EINVAL; }
   if (d->layer_norm != 0 && d->layer_norm != 1) { set_error("layer_norm %d invalid", d->layer_norm); return FRL_EINVAL; }
   if (d->layer_norm) {
     if (d->dtype != FRL_DTYPE_F32) { set_error("layer_norm: f32 kernel only"); return FRL_EUNSUPPORTED; }
-    if (d->tile_policy == FRL_TILE_LATENCY) { set_error("layer_norm: the latency build has no LayerNorm pass (use AUTO / THROUGHPUT)"); return FRL_EUNSUPPORTED; }
+    if (d->tile_policy >= FRL_TILE_LATENCY) { set_error("layer_norm: the latency build has no LayerNorm pass (use AUTO / THROUGHPUT)"); return FRL_EUNSUPPORTED; }
   }
   if (d->rng_impl < FRL_RNG_NONE || d->rng_impl > FRL_RNG_THREEFRY_LEGACY) { set_error("rng_impl %d invalid", d->rng_impl); return FRL_EINVAL; }
   if (d->rng_impl == FRL_RNG_THREEFRY_LEGACY && (long long)d->n_states * d->particles * d->x_dim > 0xFFFFFFFFll) {

@@ -270,7 +270,7 @@ void set_error(const char* fmt, ...);
 int launch_prepare(const PArgs& a, hipStream_t stream);
 int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);   // LDS K-slab variant (H = 256 only), A/B reference
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
-template <int ACT> int launch_sampler_lat_act(const KArgs& a, hipStream_t stream); // latency variant (4 waves per tile), one TU per activation
+template <int ACT> int launch_sampler_lat_act(const KArgs& a, int tile_rows, hipStream_t stream); // latency variant (4 waves per tile), one TU per activation
 // CU count of the current device (cached per thread and device)
 inline int device_cus() {
   static thread_local int cus[16] = {0};
@@ -294,6 +294,10 @@ inline bool sampler_lat_supports(const KArgs& a) {
   const int ar = 4 * ((a.A + 7) / 8), ck = (a.C + 1) / 2;
   return (a.H == 256 || a.H == 512) && ((ar <= 4 && ck <= 12) || (ar <= 12 && ck <= 64)) && a.XR >= 2 * ar &&
          lat_lds_bytes(a.NE, a.L, a.H, false) <= 160 * 1024;
+}
+// the 16-chain-tile build (MFMA 16x16x4): x rows ROWR(n) + 4 s of four k-steps cover 16 action rows; cond k-steps of 4 rows
+inline bool sampler_lat16_supports(const KArgs& a) {
+  return a.H == 256 && a.A <= 16 && (a.C + 3) / 4 <= 32 && lat_lds_bytes(a.NE, a.L, a.H, false) <= 160 * 1024;
 }
 int launch_prepare_bf16(const FrlParams& p, const Plan& pl, float* ws, hipStream_t stream);   // bf16 weight stream image
 int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256)

@@ -38,15 +38,16 @@ template <> struct WVec<4> {
   }
 };
 
-template <int H, int ACT, int NRX, int CKMAX>
+template <int TR, int H, int ACT, int NRX, int CKMAX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_lat_kernel(const KArgs a) {
-  typedef Geo<32> G;
-  typedef f32x16 acc_t;
-  constexpr int TR = 32, NR = 16;
-  constexpr int NBW = H / 128;      // 32-row output blocks per wave
+  typedef Geo<TR> G;                // 32: MFMA 32x32x2, 16: MFMA 16x16x4 (tiles of 16 chains: half the latency again)
+  typedef typename G::acc_t acc_t;
+  constexpr int NR = G::NR, KS = G::KS;
+  constexpr int NBW = H / (4 * TR); // TR-row output blocks per wave
   constexpr int FW = H / 4;         // features per wave
-  constexpr int NK = H / 2;         // k-steps per hidden layer
+  constexpr int NK = H / KS;        // k-steps per hidden layer
+  static_assert(NBW % KS == 0 && NRX <= NR, "geometry");
   constexpr int ROWB = H * 4;
   constexpr int RW = 16;            // hidden-layer weight ring (k-steps ahead)
   constexpr int R0 = 4;             // Dense_0 weight ring
@@ -57,7 +58,7 @@ frl_sampler_lat_kernel(const KArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, ls = lane >> 5;
+  const int li = lane % TR, ls = lane / TR;
 
   float* s_tb = (float*)smem;                         // [NE][H] (absent when a.lat_tb_global)
   float* s_bh = s_tb + (a.lat_tb_global ? 0 : a.NE * H);   // [L-1][H]
@@ -113,7 +114,7 @@ frl_sampler_lat_kernel(const KArgs a) {
     float cb[CKMAX];
     sfor<CKMAX>([&](auto CI) {
       constexpr int c = decltype(CI)::value;
-      const int k = 2 * c + ls;
+      const int k = KS * c + ls;
       cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
     });
     float aux[NRX];
@@ -156,7 +157,7 @@ frl_sampler_lat_kernel(const KArgs a) {
         auto l0load = [&](auto NI) {
           constexpr int n = decltype(NI)::value;
           if constexpr (n < NRX) r0[n % R0] = WV::ld(rs0, voff_x, G::rowr(n) * ROWB);
-          else r0[n % R0] = WV::ld(rs0, voff_h, (a.XR + 2 * (n - NRX)) * ROWB);
+          else r0[n % R0] = WV::ld(rs0, voff_h, (a.XR + KS * (n - NRX)) * ROWB);
         };
         sfor<R0 - 1>([&](auto NI) { l0load(NI); });
         sfor<N0>([&](auto NI) {
@@ -178,14 +179,14 @@ frl_sampler_lat_kernel(const KArgs a) {
         // the layer's first weight k-steps are requested before the activation math, which hides their L2 latency
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
         wv_t ring[RW];
-        sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs, voff_h, 2 * k * ROWB); });
+        sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs, voff_h, KS * k * ROWB); });
         sfor<NBW>([&](auto JI) {
           constexpr int jb = decltype(JI)::value;
           sfor<NR>([&](auto RI) {
             constexpr int r = decltype(RI)::value;
-            // feature f = FW w + NBW row + jb is contracted by k-step f >> 1 on lane half f & 1 (NBW is even)
-            const int ks = (FW / 2) * wave + (NBW / 2) * (G::rowr(r) + 4 * ls) + (jb >> 1);
-            abuf[(((ks >> 2) * 64) + (jb & 1) * 32 + li) * 4 + (ks & 3)] = act_fn<ACT>(acc[jb][r]);
+            // feature f = FW w + NBW row + jb is contracted by k-step f / KS on lane group f % KS (KS divides NBW)
+            const int ks = (FW / KS) * wave + (NBW / KS) * (G::rowr(r) + 4 * ls) + (jb / KS);
+            abuf[(((ks >> 2) * 64) + (jb % KS) * TR + li) * 4 + (ks & 3)] = act_fn<ACT>(acc[jb][r]);
           });
         });
         sfor<NR>([&](auto RI) {
@@ -198,7 +199,7 @@ frl_sampler_lat_kernel(const KArgs a) {
         f32x4 bq = bsrc[0], bqn = bq;
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
-          if constexpr (k + RW - 1 < NK) ring[(k + RW - 1) % RW] = WV::ld(rs, voff_h, 2 * (k + RW - 1) * ROWB);
+          if constexpr (k + RW - 1 < NK) ring[(k + RW - 1) % RW] = WV::ld(rs, voff_h, KS * (k + RW - 1) * ROWB);
           if constexpr ((k & 3) == 0 && k + 4 < NK) bqn = bsrc[(k / 4 + 1) * 64];
           const wv_t aw = ring[k % RW];
           const float bop = bq[k & 3];
@@ -301,10 +302,12 @@ frl_sampler_lat_kernel(const KArgs a) {
   }
 }
 
-template <int H, int ACT, int NRX, int CKMAX>
+template <int TR, int H, int ACT, int NRX, int CKMAX>
 static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
-  auto kern = frl_sampler_lat_kernel<H, ACT, NRX, CKMAX>;
-  const long long ntiles = (a.B + 31) / 32;
+  auto kern = frl_sampler_lat_kernel<TR, H, ACT, NRX, CKMAX>;
+  a.AR = 4 * ((a.A + 4 * Geo<TR>::KS - 1) / (4 * Geo<TR>::KS));   // x k-steps: four of them contract 4 KS rows (ROWR(n) + 4 s)
+  a.CK = (a.C + Geo<TR>::KS - 1) / Geo<TR>::KS;
+  const long long ntiles = (a.B + TR - 1) / TR;
   const int grid = (int)(ntiles < 4LL * ncu ? ntiles : 4LL * ncu);
   a.lat_tb_global = lat_lds_bytes(a.NE, a.L, H, true) > 160 * 1024 ? 1 : 0;
   const size_t lds = lat_lds_bytes(a.NE, a.L, H, !a.lat_tb_global);
@@ -317,22 +320,27 @@ static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
   return FRL_OK;
 }
 
+// tile_rows: 0 = choose (16-chain tiles while they still give every CU at most one tile), 16 / 32 = forced
 template <int ACT>
-int launch_sampler_lat_act(const KArgs& a0, hipStream_t stream) {
+int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
   KArgs a = a0;
-  a.AR = 4 * ((a.A + 7) / 8);
-  a.CK = (a.C + 1) / 2;
   const int ncu = device_cus();
-  const bool narrow = a.AR <= 4 && a.CK <= 12;
-  if (a.H == 256) return narrow ? launch_lat_inst<256, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<256, ACT, 12, 64>(a, ncu, stream);
-  if (a.H == 512) return narrow ? launch_lat_inst<512, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<512, ACT, 12, 64>(a, ncu, stream);
-  set_error("latency sampler: hidden width %d has no kernel", a.H);
-  return FRL_EUNSUPPORTED;
+  const bool can16 = sampler_lat16_supports(a), can32 = sampler_lat_supports(a);
+  bool use16 = can16 && (a.B + 15) / 16 <= ncu;
+  if (tile_rows == 16) use16 = true; else if (tile_rows == 32) use16 = false;
+  if (use16 ? !can16 : !can32) { set_error("latency sampler: no %d-chain-tile build for this configuration (H %d, x_dim %d, operand cond rows %d)", use16 ? 16 : 32, a.H, a.A, a.C); return FRL_EUNSUPPORTED; }
+  if (use16) {
+    const bool narrow = (a.C + 3) / 4 <= 12;
+    return narrow ? launch_lat_inst<16, 256, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<16, 256, ACT, 4, 32>(a, ncu, stream);
+  }
+  const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;
+  if (a.H == 256) return narrow ? launch_lat_inst<32, 256, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<32, 256, ACT, 12, 64>(a, ncu, stream);
+  return narrow ? launch_lat_inst<32, 512, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<32, 512, ACT, 12, 64>(a, ncu, stream);
 }
 
 #ifndef FRL_RS_ACT
 #error "compile with -DFRL_RS_ACT=<FRL_ACT_*>: one translation unit per activation"
 #endif
-template int launch_sampler_lat_act<FRL_RS_ACT>(const KArgs&, hipStream_t);
+template int launch_sampler_lat_act<FRL_RS_ACT>(const KArgs&, int, hipStream_t);
 
 }  // namespace frl

@@ -17,7 +17,7 @@ FRL_SOLVER_DDPM, FRL_SOLVER_DDIM, FRL_SOLVER_EULER, FRL_SOLVER_DPM2, FRL_SOLVER_
 FRL_TEMB_NONE, FRL_TEMB_POSITIONAL, FRL_TEMB_FOURIER = 0, 1, 2
 FRL_ACT = {"mish": 0, "silu": 1, "relu": 2, "gelu_tanh": 3, "gelu": 3, "tanh": 4, "elu": 5}
 FRL_DTYPE_F32, FRL_DTYPE_BF16 = 0, 1
-FRL_TILE = {"auto": 0, "throughput": 1, "latency": 2}
+FRL_TILE = {"auto": 0, "throughput": 1, "latency": 2, "latency32": 3, "latency16": 4}
 FRL_RNG = {"none": 0, "partitionable": 1, "legacy": 2}   # jax.random threefry layouts (include/flowrl_hip.h FRL_RNG_*)
 
 FRL_OK, FRL_EINVAL, FRL_EUNSUPPORTED, FRL_EWORKSPACE, FRL_EHIP = 0, -1, -2, -3, -4

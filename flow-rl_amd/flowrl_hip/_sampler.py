@@ -118,7 +118,7 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
     d.dtype = _lib.FRL_DTYPE_BF16 if compute_dtype == "bf16" else _lib.FRL_DTYPE_F32
     d.want_history = 1 if want_history else 0
     if tile_policy not in _lib.FRL_TILE:
-        raise ValueError(f"tile_policy {tile_policy!r}: 'auto', 'throughput' (one wave per tile) or 'latency' (four waves per tile)")
+        raise ValueError(f"tile_policy {tile_policy!r}: 'auto', 'throughput' (one wave per tile), 'latency' (four waves per tile) or 'latency32' / 'latency16' (that build on 32- / 16-chain tiles)")
     d.tile_policy = _lib.FRL_TILE[tile_policy]
     d.rng_impl = int(rng_impl)
     d.layer_norm = 1 if pred.layer_norm else 0     # Dense -> LayerNorm -> act (mlp.py:26-29)

@@ -23,10 +23,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.fixture(params=["throughput", "latency"], autouse=True)
+@pytest.fixture(params=["throughput", "latency32", "latency16"], autouse=True)
 def _tile_policy(request):
-    """Every case below runs under both f32 builds: one wave per tile (sampler_rs.hip) and four waves per tile
-    (sampler_lat.hip).  `auto` would pick the latency build for all of these small batches."""
+    """Every case below runs under all three f32 builds: one wave per tile (sampler_rs.hip) and four waves per tile
+    (sampler_lat.hip) on 32- and on 16-chain tiles.  `auto` would pick a latency build for all of these small batches.
+    The 16-chain build covers x_dim <= 16, hidden width 256 and <= 128 condition rows in the operand: beyond that a
+    forced call must be refused loudly (and `auto` / `latency` take another build)."""
     global TILE
     TILE = request.param
     yield
@@ -39,6 +41,11 @@ def _check(case, history=True):
     import dataclasses
     case = dataclasses.replace(case, tile=TILE)
     params, xT, cond, noise = H.make_inputs(case)
+    if TILE == "latency16" and (case.A > 16 or any(h != 256 for h in case.hidden)):
+        import flowrl_hip as fh
+        with pytest.raises(fh.FlowRLHipUnsupported):
+            H.product_run(case, H.product_model(case, params), xT, cond, noise, history=history)
+        return
     ref0, refx, refe = H.oracle_run(case, params, xT, cond, noise, dtype=np.float64)
     model = H.product_model(case, params)
     x0, xh, eh = H.product_run(case, model, xT, cond, noise, history=history)
@@ -262,7 +269,7 @@ def test_layer_norm_backbones():
         H.Case("ln-one-hidden-relu", "ddpm", A=2, S=0, T=6, B=33, hidden=(256,), act="relu", schedule="linear", ln=True, seed=44),
         H.Case("ln-dpmpp2m", "cddpm", A=3, S=11, T=6, B=64, temb="learnable_fourier", schedule="cosine", solver="dpm++2m", ln=True, seed=45),
     ]
-    if TILE == "latency":
+    if TILE.startswith("latency"):
         with pytest.raises(fh.FlowRLHipUnsupported):
             _check(cases[0])
         return
