@@ -49,8 +49,10 @@ frl_sampler_lat_kernel(const KArgs a) {
   constexpr int NK = H / KS;        // k-steps per hidden layer
   static_assert(NBW % KS == 0 && NRX <= NR, "geometry");
   constexpr int ROWB = H * 4;
-  constexpr int RW = 16;            // hidden-layer weight ring (k-steps ahead)
-  constexpr int R0 = 4;             // Dense_0 weight ring
+  constexpr int RW = (TR == 16) ? 32 : 16;   // hidden-layer weight ring (k-steps ahead): lookahead of ~2000 MFMA cycles either way
+  constexpr int N0 = NRX + CKMAX;            // Dense_0 k-step slots
+  constexpr int R0 = N0 < 16 ? N0 : 16;      // Dense_0 weight ring: requested a whole step ahead (below), so its L2 latency
+                                             // never sits between the epilogue of one step and the first MFMA of the next
   typedef WVec<NBW> WV;
   typedef typename WV::type wv_t;
 
@@ -99,6 +101,21 @@ frl_sampler_lat_kernel(const KArgs a) {
   }
 
   const int ntiles = (int)((a.B + TR - 1) / TR);
+  // Dense_0 operands never depend on the data: the first R0 - 1 k-steps of the NEXT evaluation are requested before
+  // Dense_L and the epilogue of the current one (and before the first tile here)
+  wv_t r0[R0];
+  auto l0load = [&](auto NI) {
+    constexpr int n = decltype(NI)::value;
+    if constexpr (n < NRX) r0[n % R0] = WV::ld(rs0, voff_x, G::rowr(n) * ROWB);
+    else r0[n % R0] = WV::ld(rs0, voff_h, (a.XR + KS * (n - NRX)) * ROWB);
+  };
+  sfor<R0 - 1>([&](auto NI) { l0load(NI); });
+  static_assert(NK % RW == 0, "a layer's tail prefetch must land in the ring slots the next layer reads first");
+  wv_t ring[RW];
+  if (a.L > 1) {
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh[0], 0, H * ROWB, 0x00020000);
+    sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs1, voff_h, KS * k * ROWB); });
+  }
   int phase = 0;   // runs on across steps and tiles
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long chain = (long long)tile * TR + li;
@@ -152,14 +169,6 @@ frl_sampler_lat_kernel(const KArgs a) {
         zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
       });
       {
-        constexpr int N0 = NRX + CKMAX;
-        wv_t r0[R0];
-        auto l0load = [&](auto NI) {
-          constexpr int n = decltype(NI)::value;
-          if constexpr (n < NRX) r0[n % R0] = WV::ld(rs0, voff_x, G::rowr(n) * ROWB);
-          else r0[n % R0] = WV::ld(rs0, voff_h, (a.XR + KS * (n - NRX)) * ROWB);
-        };
-        sfor<R0 - 1>([&](auto NI) { l0load(NI); });
         sfor<N0>([&](auto NI) {
           constexpr int n = decltype(NI)::value;
           if constexpr (n + R0 - 1 < N0) l0load(std::integral_constant<int, n + R0 - 1>{});
@@ -176,10 +185,11 @@ frl_sampler_lat_kernel(const KArgs a) {
       // ---------------- hidden layers: activations through LDS, one barrier each ------------------------
       for (int l = 1; l < a.L; ++l) {
         float* abuf = s_act + (phase++ & 1) * (H * TR);
-        // the layer's first weight k-steps are requested before the activation math, which hides their L2 latency
+        // this layer's first RW - 1 weight k-steps are already in flight (requested by the tail of the previous layer's
+        // loop); its own tail requests the next layer's — after the last hidden layer the FIRST one's again (next
+        // evaluation / tile) — so no L2 latency sits between a barrier and the first MFMA behind it
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
-        wv_t ring[RW];
-        sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = WV::ld(rs, voff_h, KS * k * ROWB); });
+        const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, (l + 1 < a.L) ? l : 0), 0, H * ROWB, 0x00020000);
         sfor<NBW>([&](auto JI) {
           constexpr int jb = decltype(JI)::value;
           sfor<NR>([&](auto RI) {
@@ -200,6 +210,7 @@ frl_sampler_lat_kernel(const KArgs a) {
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr (k + RW - 1 < NK) ring[(k + RW - 1) % RW] = WV::ld(rs, voff_h, KS * (k + RW - 1) * ROWB);
+          else ring[(k + RW - 1) % RW] = WV::ld(rsn, voff_h, KS * (k + RW - 1 - NK) * ROWB);
           if constexpr ((k & 3) == 0 && k + 4 < NK) bqn = bsrc[(k / 4 + 1) * 64];
           const wv_t aw = ring[k % RW];
           const float bop = bq[k & 3];
@@ -207,6 +218,8 @@ frl_sampler_lat_kernel(const KArgs a) {
           if constexpr ((k & 3) == 3) bq = bqn;
         });
       }
+
+      sfor<R0 - 1>([&](auto NI) { l0load(NI); });   // next evaluation's (or tile's) Dense_0 operands
 
       // ---------------- Dense_L, split-K over the waves ------------------------------------------------------
       acc_t O;
