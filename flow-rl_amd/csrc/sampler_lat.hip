@@ -190,15 +190,30 @@ frl_sampler_lat_kernel(const KArgs a) {
         // evaluation / tile) — so no L2 latency sits between a barrier and the first MFMA behind it
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, (l + 1 < a.L) ? l : 0), 0, H * ROWB, 0x00020000);
-        sfor<NBW>([&](auto JI) {
-          constexpr int jb = decltype(JI)::value;
-          sfor<NR>([&](auto RI) {
-            constexpr int r = decltype(RI)::value;
-            // feature f = FW w + NBW row + jb is contracted by k-step f / KS on lane group f % KS (KS divides NBW)
-            const int ks = (FW / KS) * wave + (NBW / KS) * (G::rowr(r) + 4 * ls) + (jb / KS);
-            abuf[(((ks >> 2) * 64) + (jb % KS) * TR + li) * 4 + (ks & 3)] = act_fn<ACT>(acc[jb][r]);
+        // feature f = FW w + NBW row + jb is contracted by k-step ks = f / KS on lane group f % KS (KS divides NBW).
+        if constexpr (NBW == KS) {
+          // ks = (FW / KS) w + ROWR(r) + 4 s: registers r = 4 q .. 4 q + 3 are the four k-steps of ONE 16-byte group of
+          // this lane's column — one conflict-free ds_write_b128 instead of four strided ds_write_b32
+          sfor<NBW>([&](auto JI) {
+            constexpr int jb = decltype(JI)::value;
+            sfor<NR / 4>([&](auto QI) {
+              constexpr int q = decltype(QI)::value;
+              const int ks = (FW / KS) * wave + G::rowr(4 * q) + 4 * ls;
+              f32x4 v;
+              sfor<4>([&](auto EI) { constexpr int e = decltype(EI)::value; v[e] = act_fn<ACT>(acc[jb][4 * q + e]); });
+              *(f32x4*)(abuf + (((ks >> 2) * 64) + jb * TR + li) * 4) = v;
+            });
           });
-        });
+        } else {
+          sfor<NBW>([&](auto JI) {
+            constexpr int jb = decltype(JI)::value;
+            sfor<NR>([&](auto RI) {
+              constexpr int r = decltype(RI)::value;
+              const int ks = (FW / KS) * wave + (NBW / KS) * (G::rowr(r) + 4 * ls) + (jb / KS);
+              abuf[(((ks >> 2) * 64) + (jb % KS) * TR + li) * 4 + (ks & 3)] = act_fn<ACT>(acc[jb][r]);
+            });
+          });
+        }
         sfor<NR>([&](auto RI) {
           constexpr int r = decltype(RI)::value;
           const wv_t bv = *(const wv_t*)(s_bh + (l - 1) * H + FW * wave + NBW * (G::rowr(r) + 4 * ls));
