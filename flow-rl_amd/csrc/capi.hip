@@ -253,6 +253,11 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
   const bool needs_noise = (desc->kind != FRL_KIND_CNF) && desc->solver == FRL_SOLVER_DDPM;
   const bool rng = desc->rng_impl != FRL_RNG_NONE;
+  if (rng && bufs->rng_total_chains != 0 &&
+      (bufs->rng_chain_offset < 0 || bufs->rng_chain_offset + pl.B > bufs->rng_total_chains)) {
+    set_error("bufs.rng_chain_offset %lld + %lld chains exceeds rng_total_chains %lld", (long long)bufs->rng_chain_offset, pl.B, (long long)bufs->rng_total_chains); return FRL_EINVAL; }
+  if (rng && desc->rng_impl == FRL_RNG_THREEFRY_LEGACY && bufs->rng_total_chains * desc->x_dim > 0xFFFFFFFFll) {
+    set_error("legacy threefry layout: at most 2^32 - 1 elements per draw"); return FRL_EUNSUPPORTED; }
   if (rng && bufs->rng_key == nullptr) { set_error("desc.rng_impl = %d but bufs.rng_key is NULL", desc->rng_impl); return FRL_EINVAL; }
   if (needs_noise && !rng && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step (or set desc.rng_impl and bufs.rng_key)"); return FRL_EINVAL; }
   if (desc->want_history && (bufs->xt_hist == nullptr || bufs->eps_hist == nullptr)) { set_error("want_history set but xt_hist / eps_hist is NULL"); return FRL_EINVAL; }
@@ -273,7 +278,11 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
     uint32_t* keys = (uint32_t*)((float*)workspace + pl.off_keys);
     rc = launch_rng_chain(bufs->rng_key, desc->rng_impl, pl.mode, pl.T, keys, bufs->rng_out, (hipStream_t)hip_stream);
     if (rc != FRL_OK) return rc;
-    if (draw) { a.rng_keys = keys; a.rng_impl = desc->rng_impl; }
+    if (draw) {
+      a.rng_keys = keys; a.rng_impl = desc->rng_impl;
+      a.rng_off = bufs->rng_total_chains > 0 ? bufs->rng_chain_offset : 0;
+      a.rng_total = bufs->rng_total_chains > 0 ? bufs->rng_total_chains : pl.B;
+    }
   }
   if (desc->cond_embed) {
     // cond_embedding MLP once per state (ddpm.py:89-90), into the workspace; the sampler then reads those rows

@@ -143,6 +143,7 @@ struct KArgs {
   const float* wl_raw;                    // Dense_L kernel (H, AO) in place (latency kernel)
   const uint32_t* rng_keys;               // [NE][2] iteration keys (rng_impl != FRL_RNG_NONE), else NULL
   int rng_impl;
+  long long rng_off, rng_total;           // first chain of this call in the unsharded batch / its chain count (draw indices)
   const float* ws_ln;                     // [L][2][H] LayerNorm scale | bias of every hidden layer, or NULL (no LayerNorm)
   int lat_tb_global;                      // latency kernel: time-bias rows read from the workspace, not staged in LDS
   const float* state_bias;                // MODE_EVAL: [n_states][H] Dense_0 accumulator init per STATE (hoisted obs rows) or NULL

@@ -314,7 +314,7 @@ frl_sampler_bf16_kernel(const KArgs a) {
         float z = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         if (a.rng_impl != FRL_RNG_NONE && in && c5 != 0.0f) {   // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai]; the
                                                                    // last iteration multiplies its draw by 0 (ddpm.py:206): skipped
-          z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai);
+          z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai);
           __builtin_amdgcn_sched_barrier(0);       // one draw at a time: interleaved draws cost registers the hot loop needs
         }
         if (a.xt_hist != nullptr && in) {

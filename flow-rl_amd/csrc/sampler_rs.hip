@@ -197,7 +197,7 @@ frl_sampler_rs_kernel(const KArgs a) {
           sfor<NRX>([&](auto RI) {
             constexpr int r = decltype(RI)::value;
             const int ai = G::rowr(r) + 4 * ls;
-            zr[r] = (used && valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.B * a.A, (unsigned long long)chain * a.A + ai) : 0.0f;
+            zr[r] = (used && valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai) : 0.0f;
           });
         }
       }

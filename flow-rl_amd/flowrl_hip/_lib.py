@@ -52,7 +52,7 @@ class FrlSchedule(C.Structure):
 
 class FrlFwdBufs(C.Structure):
     _fields_ = [("xT", _fp), ("cond", _fp), ("noise", _fp), ("x0", _fp), ("xt_hist", _fp), ("eps_hist", _fp),
-                ("rng_key", _fp), ("rng_out", _fp)]
+                ("rng_key", _fp), ("rng_out", _fp), ("rng_chain_offset", C.c_int64), ("rng_total_chains", C.c_int64)]
 
 
 class FrlBwdBufs(C.Structure):

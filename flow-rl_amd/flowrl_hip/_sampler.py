@@ -226,8 +226,10 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
                 compute_dtype: str = "f32", tile_policy: str = "auto", rng_key: Optional[torch.Tensor] = None,
-                rng_impl: Optional[str] = None, cache_prepare: bool = True):
-    """Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored — and, when ``rng_key`` (a (2,)
+                rng_impl: Optional[str] = None, cache_prepare: bool = True, rng_shard: Optional[Tuple[int, int]] = None):
+    """``rng_shard`` = (first chain, total chains) when this call is one state-shard of a larger batch: the in-kernel
+    draws are then the elements of the UNSHARDED normal(key_j, (total, A)), so N ranks reproduce one big call.
+    Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored — and, when ``rng_key`` (a (2,)
     uint32 threefry key, flowrl_hip.random) is given, a third element: the rng the reference's sample() returns; the
     per-step noise is then drawn in-kernel unless ``noise`` is passed.  ``compute_dtype`` = "bf16"
     selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful)."""
@@ -259,6 +261,8 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
         rng_key = _random.as_key(rng_key, device)
         rng_out = torch.empty((2,), dtype=torch.uint32, device=device)
         bufs.rng_key, bufs.rng_out = rng_key.data_ptr(), rng_out.data_ptr()
+        if rng_shard is not None:
+            bufs.rng_chain_offset, bufs.rng_total_chains = int(rng_shard[0]), int(rng_shard[1])
     xt_hist = eps_hist = None
     if history:
         xt_hist = torch.empty((steps, B, A), dtype=torch.float32, device=device)

@@ -40,18 +40,25 @@ def all_gather_ragged(local: torch.Tensor, counts: Sequence[int], group=None) ->
 
 
 def sample_sharded(sample_fn: Callable, xT: torch.Tensor, condition: Optional[torch.Tensor],
-                   noise: Optional[torch.Tensor], particles: int = 1, group=None, gather: bool = True):
+                   noise: Optional[torch.Tensor], particles: int = 1, group=None, gather: bool = True, keyed: bool = False):
     """Run ``sample_fn(xT_shard, cond_shard, noise_shard) -> x0_shard`` on this rank's block of states and
     all-gather the result.  Global layouts: xT (n_states*particles, A), condition (n_states, C) un-repeated,
     noise (T, n_states*particles, A).  Every rank passes the same global tensors (or at least its own block
-    at the right offsets) and receives the full x0 when ``gather`` is set, else its own shard."""
+    at the right offsets) and receives the full x0 when ``gather`` is set, else its own shard.  ``keyed``: the third
+    argument handed to ``sample_fn`` is ``rng_shard`` = (first chain, total chains) for ``model.sample(key, ..., rng_shard=)``
+    instead of a noise block."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_states = xT.shape[0] // particles
     lo, hi = shard_bounds(n_states, rank, world)
     clo, chi = lo * particles, hi * particles
-    x0 = sample_fn(xT[clo:chi], None if condition is None else condition[lo:hi],
-                   None if noise is None else noise[:, clo:chi])
+    if keyed:
+        # rng-in / rng-out sharding: every rank passes the SAME key; its draws are the elements [clo, chi) of the unsharded
+        # normal(key_j, (B, A)) (FrlFwdBufs.rng_chain_offset / rng_total_chains), so the gathered x0 is the single-GPU call's
+        x0 = sample_fn(xT[clo:chi], None if condition is None else condition[lo:hi], (clo, xT.shape[0]))
+    else:
+        x0 = sample_fn(xT[clo:chi], None if condition is None else condition[lo:hi],
+                       None if noise is None else noise[:, clo:chi])
     if world == 1 or not gather:
         return x0
     counts = [(shard_bounds(n_states, r, world)[1] - shard_bounds(n_states, r, world)[0]) * particles for r in range(world)]

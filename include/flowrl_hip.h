@@ -158,6 +158,11 @@ typedef struct FrlFwdBufs {
   const uint32_t* rng_key; /* device (2,) uint32: the `rng` argument of sample() (a raw threefry key, as
                               jax.random.key_data gives it); used when desc.rng_impl != FRL_RNG_NONE, else ignored */
   uint32_t* rng_out;       /* device (2,) uint32 or NULL: the rng sample() returns (after the scan's splits)     */
+  int64_t rng_chain_offset; /* keyed calls on a SHARD of the batch (one rank of a state-sharded job): index of this call's
+                               first chain in the unsharded batch, and ...                                          */
+  int64_t rng_total_chains; /* ... the unsharded batch's chain count (0 = this call is the whole batch).  The draw of
+                               chain c, row a is element (offset + c) * A + a of normal(key_j, (total, A)), so the
+                               shards together reproduce the reference's single call bit for bit                    */
 } FrlFwdBufs;
 
 /* FRL_OK if this build has a kernel for `desc`, else FRL_EINVAL / FRL_EUNSUPPORTED (message set). */

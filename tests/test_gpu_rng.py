@@ -221,3 +221,30 @@ def test_sample_and_select_rng_in_rng_out(temperature):
     torch.cuda.synchronize()
     assert np.array_equal(rng_out.cpu().numpy(), rng)
     np.testing.assert_allclose(best.cpu().numpy()[clear], want[clear], atol=1e-4)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_keyed_shards_reproduce_the_unsharded_call(impl):
+    """State-sharded keyed sampling (flowrl_hip.parallel.sample_sharded(keyed=True) on N ranks): each shard draws the
+    elements [first chain, first chain + its chains) of the UNSHARDED normal(key_j, (B, A)) — bufs.rng_chain_offset /
+    rng_total_chains — so the shards together are the single call, bit for bit (same build forced on both sides)."""
+    import torch
+    case = H.Case("shard", "ddpm", A=3, S=11, T=5, B=6 * 50, particles=50, seed=13, tile="throughput")
+    params, xT, cond, _ = H.make_inputs(case)
+    model = H.product_model(case, params)
+    key = _key(4242)
+    kw = dict(particles=50, tile_policy="throughput", rng_impl=impl)
+    rng_full, full, _ = model.sample(key, _t(xT), _t(cond), False, "ddpm", **kw)
+    parts = []
+    for lo, hi in ((0, 1), (1, 4), (4, 6)):                       # ragged state shards
+        rng_s, x0, _ = model.sample(key, _t(xT[lo * 50:hi * 50]), _t(cond[lo:hi]), False, "ddpm", rng_shard=(lo * 50, case.B), **kw)
+        assert torch.equal(rng_s, rng_full)                       # every shard returns the same advanced rng
+        parts.append(x0)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts), full)
+    # without the offsets a shard is its own batch: different draws
+    _, alone, _ = model.sample(key, _t(xT[50:200]), _t(cond[1:4]), False, "ddpm", **kw)
+    assert not torch.equal(alone, full[50:200])
+    import flowrl_hip as fh
+    with pytest.raises(fh.FlowRLHipError):
+        model.sample(key, _t(xT[:50]), _t(cond[:1]), False, "ddpm", rng_shard=(case.B - 10, case.B), **kw)
