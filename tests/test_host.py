@@ -139,6 +139,22 @@ def _gloo_worker(rank, world, port, n_states, particles, out_dir):
         mine = parallel.sample_sharded(fake_sampler, xT, cond, noise, particles=particles, gather=False)
         lo, hi = parallel.shard_bounds(n_states, rank, world)
         assert torch.equal(mine, want[lo * particles: hi * particles])
+        # keyed sharding: the third argument becomes rng_shard = (first chain, total chains); a stand-in that draws the
+        # elements [first, first + n) of the unsharded normal(key, (B, A)) — what FrlFwdBufs.rng_chain_offset /
+        # rng_total_chains make the kernel do — must gather to the single-call result
+        import numpy as np
+        import threefry_oracle as tf
+        key = tf.prng_key(7)
+
+        def keyed_sampler(x, c, shard):
+            first, total = shard
+            assert total == n_states * particles
+            z = tf.normal(key, (total, A))[first:first + x.shape[0]]
+            return x + torch.from_numpy(z) + c.repeat_interleave(particles, 0)[:, :A]
+
+        got = parallel.sample_sharded(keyed_sampler, xT, cond, None, particles=particles, keyed=True)
+        want_k = keyed_sampler(xT, cond, (0, n_states * particles))
+        assert torch.equal(got, want_k), f"rank {rank}: keyed sharded result differs"
         Path(out_dir, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
