@@ -91,7 +91,7 @@ def sample(model, w, xT, cond, noise):
     if w.get("rng", "none") != "none":
         from flowrl_hip import random as fr
         key = fr.PRNGKey(0, xT.device)
-        return model.sample(key, xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"], cache_prepare=w.get("cache_prepare", False))[1]
+        return model.sample(key, xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"], cache_prepare=w.get("cache_prepare", False), rng_shard=w.get("rng_shard"))[1]
     return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), cache_prepare=w.get("cache_prepare", False))[1]
 
 
@@ -283,6 +283,7 @@ def main():
     w["dtype"] = args.dtype
     w["tile_policy"] = args.tile_policy
     w["rng"] = args.rng
+    w["rng_shard"] = None   # set below for N > 1: every rank draws its block of the job-wide normal(key_j, (N B, A))
     w["cache_prepare"] = bool(args.cache_prepare)
     if args.act:
         w["act"] = args.act
@@ -298,6 +299,8 @@ def main():
         return
     xT, cond, noise = make_inputs(w, dev, 1234 + rank)       # this rank's shard of the states
     gathered = torch.empty((world * B, A), device=dev) if world > 1 else None
+    if world > 1 and args.rng != "none":
+        w["rng_shard"] = (rank * B, world * B)
 
     vjp = bool(w.get("vjp"))
     g_x0 = torch.randn((B, A), generator=torch.Generator(device=dev).manual_seed(99 + rank), device=dev) / (world * B) if vjp else None
