@@ -30,7 +30,7 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
                                     : (sampler_lat_supports(a) || sampler_lat16_supports(a));
     if (!ok) { set_error("tile_policy %d: this configuration has no such latency build (H %d, x_dim %d, operand cond rows %d, x rows %d, evaluations %d, LDS %zu bytes)", tile_policy, a.H, a.A, a.C, a.XR, a.NE, lat_lds_bytes(a.NE, a.L, a.H, false)); return FRL_EUNSUPPORTED; }
     lat = true;
-  } else if (tile_policy == FRL_TILE_AUTO && a.ws_ln == nullptr) {
+  } else if (tile_policy == FRL_TILE_AUTO) {
     // Measured on MI355X (cfg2 geometry, scripts/sweep_tile.sh): one round of latency-build tiles (one per CU) takes
     // 0.12 ms, one round of throughput-build tiles (four per CU) 0.38 ms.  The latency build wins whenever its
     // rounds cost less, i.e. for small batches and for batches whose last throughput round would be mostly empty;
@@ -90,7 +90,6 @@ static int validate_desc(const FrlDesc* d) {
   if (d->layer_norm != 0 && d->layer_norm != 1) { set_error("layer_norm %d invalid", d->layer_norm); return FRL_EINVAL; }
   if (d->layer_norm) {
     if (d->dtype != FRL_DTYPE_F32) { set_error("layer_norm: f32 kernel only"); return FRL_EUNSUPPORTED; }
-    if (d->tile_policy >= FRL_TILE_LATENCY) { set_error("layer_norm: the latency build has no LayerNorm pass (use AUTO / THROUGHPUT)"); return FRL_EUNSUPPORTED; }
   }
   if (d->rng_impl < FRL_RNG_NONE || d->rng_impl > FRL_RNG_THREEFRY_LEGACY) { set_error("rng_impl %d invalid", d->rng_impl); return FRL_EINVAL; }
   if (d->rng_impl == FRL_RNG_THREEFRY_LEGACY && (long long)d->n_states * d->particles * d->x_dim > 0xFFFFFFFFll) {

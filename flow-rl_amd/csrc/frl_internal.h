@@ -287,18 +287,19 @@ inline int device_cus() {
 }
 
 // LDS of the latency kernel; the [NE][H] time-bias rows are staged only when they fit (else read through L2 per evaluation)
-inline size_t lat_lds_bytes(int NE, int L, int H, bool tb_rows) {
-  return sizeof(float) * ((tb_rows ? (size_t)NE * H : 0) + (size_t)(L - 1) * H + LAST_PAD + (size_t)NE * COEF_STRIDE + 2 * (size_t)H * 32);
+inline size_t lat_lds_bytes(int NE, int L, int H, bool tb_rows, bool ln = false) {
+  return sizeof(float) * ((tb_rows ? (size_t)NE * H : 0) + (size_t)(L - 1) * H + LAST_PAD + (size_t)NE * COEF_STRIDE + 2 * (size_t)H * 32 +
+                          (ln ? 256 + (size_t)L * 2 * H : 0));   // LayerNorm: per-wave partial sums + the scale | bias rows
 }
 // AR / CK in the units of the latency kernel (32x32x2: two input rows per k-step), whatever geometry the plan chose
 inline bool sampler_lat_supports(const KArgs& a) {
   const int ar = 4 * ((a.A + 7) / 8), ck = (a.C + 1) / 2;
   return (a.H == 256 || a.H == 512) && ((ar <= 4 && ck <= 12) || (ar <= 12 && ck <= 64)) && a.XR >= 2 * ar &&
-         lat_lds_bytes(a.NE, a.L, a.H, false) <= 160 * 1024;
+         lat_lds_bytes(a.NE, a.L, a.H, false, a.ws_ln != nullptr) <= 160 * 1024;
 }
 // the 16-chain-tile build (MFMA 16x16x4): x rows ROWR(n) + 4 s of four k-steps cover 16 action rows; cond k-steps of 4 rows
 inline bool sampler_lat16_supports(const KArgs& a) {
-  return a.H == 256 && a.A <= 16 && (a.C + 3) / 4 <= 32 && lat_lds_bytes(a.NE, a.L, a.H, false) <= 160 * 1024;
+  return a.H == 256 && a.A <= 16 && (a.C + 3) / 4 <= 32 && lat_lds_bytes(a.NE, a.L, a.H, false, a.ws_ln != nullptr) <= 160 * 1024;
 }
 int launch_prepare_bf16(const FrlParams& p, const Plan& pl, float* ws, hipStream_t stream);   // bf16 weight stream image
 int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256)

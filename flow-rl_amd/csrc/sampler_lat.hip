@@ -70,6 +70,10 @@ frl_sampler_lat_kernel(const KArgs a) {
   // The two s_act buffers alternate per PHASE (a hidden layer's activation exchange, or the Dense_L partial tiles
   // [4 waves][16][64], which fit one buffer): phase n writes buffer n & 1, barrier, reads it.  The other buffer was
   // last read in phase n - 1, which every wave left before it passed barrier n: one barrier per phase is enough.
+  float* s_stat = s_act + 2 * H * TR;                 // LayerNorm only: [2][4 waves][TR] per-wave partial sums
+  float* s_ln = s_stat + 256;                         // LayerNorm only: [L][2][H] scale | bias rows
+  if (a.ws_ln != nullptr)
+    for (int idx = tid; idx < a.L * 2 * H; idx += 256) s_ln[idx] = a.ws_ln[idx];
   if (!a.lat_tb_global)
     for (int idx = tid; idx < a.NE * H; idx += 256) s_tb[idx] = a.ws_tb[idx];
   for (int l = 1; l < a.L; ++l) {
@@ -182,6 +186,38 @@ frl_sampler_lat_kernel(const KArgs a) {
         });
       }
 
+      // flax.linen.LayerNorm of a finished pre-activation tile (mlp.py:26-29), features spread over the four waves: mean,
+      // then the variance about it, each a register sum + lane-group exchange + four per-wave partials through LDS
+      // (two extra barriers per layer; the partial buffers alternate, so no third one is needed)
+      auto ln_pass = [&](int l) {
+        float s1 = 0.0f;
+        sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; sfor<NR>([&](auto RI) { s1 += acc[jb][decltype(RI)::value]; }); });
+#pragma unroll
+        for (int m = TR; m < 64; m <<= 1) s1 += __shfl_xor(s1, m);
+        s_stat[wave * TR + li] = s1;
+        __syncthreads();
+        const float mean = (s_stat[li] + s_stat[TR + li] + s_stat[2 * TR + li] + s_stat[3 * TR + li]) * (1.0f / H);
+        float s2 = 0.0f;
+        sfor<NBW>([&](auto JI) {
+          constexpr int jb = decltype(JI)::value;
+          sfor<NR>([&](auto RI) { const float v = acc[jb][decltype(RI)::value] - mean; s2 = fmaf(v, v, s2); });
+        });
+#pragma unroll
+        for (int m = TR; m < 64; m <<= 1) s2 += __shfl_xor(s2, m);
+        s_stat[128 + wave * TR + li] = s2;
+        __syncthreads();
+        const float var = (s_stat[128 + li] + s_stat[128 + TR + li] + s_stat[128 + 2 * TR + li] + s_stat[128 + 3 * TR + li]) * (1.0f / H);
+        const float rstd = 1.0f / sqrtf(var + 1e-6f);
+        const float* sl = s_ln + l * 2 * H + FW * wave;
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const wv_t sc = *(const wv_t*)(sl + NBW * (G::rowr(r) + 4 * ls));
+          const wv_t bi = *(const wv_t*)(sl + H + NBW * (G::rowr(r) + 4 * ls));
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb][r] = (acc[jb][r] - mean) * (rstd * sc[jb]) + bi[jb]; });
+        });
+      };
+      if (a.ws_ln != nullptr) ln_pass(0);
+
       // ---------------- hidden layers: activations through LDS, one barrier each ------------------------
       for (int l = 1; l < a.L; ++l) {
         float* abuf = s_act + (phase++ & 1) * (H * TR);
@@ -232,6 +268,7 @@ frl_sampler_lat_kernel(const KArgs a) {
           sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; acc[jb] = G::mfma(aw[jb], bop, acc[jb]); });
           if constexpr ((k & 3) == 3) bq = bqn;
         });
+        if (a.ws_ln != nullptr) ln_pass(l);
       }
 
       sfor<R0 - 1>([&](auto NI) { l0load(NI); });   // next evaluation's (or tile's) Dense_0 operands
@@ -337,8 +374,9 @@ static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
   a.CK = (a.C + Geo<TR>::KS - 1) / Geo<TR>::KS;
   const long long ntiles = (a.B + TR - 1) / TR;
   const int grid = (int)(ntiles < 4LL * ncu ? ntiles : 4LL * ncu);
-  a.lat_tb_global = lat_lds_bytes(a.NE, a.L, H, true) > 160 * 1024 ? 1 : 0;
-  const size_t lds = lat_lds_bytes(a.NE, a.L, H, !a.lat_tb_global);
+  const bool ln = a.ws_ln != nullptr;
+  a.lat_tb_global = lat_lds_bytes(a.NE, a.L, H, true, ln) > 160 * 1024 ? 1 : 0;
+  const size_t lds = lat_lds_bytes(a.NE, a.L, H, !a.lat_tb_global, ln);
   if (lds > 160 * 1024) { set_error("latency sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }

@@ -108,7 +108,7 @@ typedef struct FrlDesc {
   int32_t rng_impl;     /* FRL_RNG_*: with a threefry layout, bufs.rng_key replaces bufs.noise and the call also produces
                            the rng the reference's sample() returns (bufs.rng_out), for every solver */
   int32_t layer_norm;   /* 1: the predictor MLP is Dense -> LayerNorm -> act (MLP(layer_norm=True), mlp.py:26-29; flax LayerNorm:
-                           eps 1e-6, fast variance E[x^2] - E[x]^2, scale and bias) — f32 throughput build, forward only */
+                           eps 1e-6, scale and bias; the variance is taken about the mean) — f32 builds, forward only */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a
