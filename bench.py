@@ -9,6 +9,12 @@ B = 262,144 chains per GPU).  Multi-GPU: one process per GPU (torch.distributed 
 sharded by state index (weak scaling: every rank owns B chains), the only collective is the final
 all-gather of x0 (BASELINE.json north_star), inside the timed region.
 
+Launching: `python bench.py --gpus N` with no WORLD_SIZE in the environment is the PARENT: before any GPU call it
+starts N rank processes of this same file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set,
+one device each), forwards rank 0's JSON line and exits with the first non-zero rank status; it fails loudly when the
+box has fewer than N GPUs.  Under `python -m torch.distributed.run ... bench.py --gpus N` the environment already
+names the rank, and the process is a rank itself (WORLD_SIZE must equal --gpus).
+
 Prints ONE JSON line on rank 0.  value = chain-steps/s = (ranks * B * T) / (time per step).
 """
 from __future__ import annotations
@@ -240,6 +246,62 @@ def cpu_baseline(w, budget_s=15.0):
                       f"one pass, {t:.2f} s, {cores} BLAS threads"}
 
 
+def launch_ranks(n: int, argv, stub: bool) -> int:
+    """Parent of a multi-GPU run: nothing here touches the GPU (torch.cuda.device_count() only counts devices on this
+    image), so the children are ordinary fresh processes — never a re-exec of a process that initialised HIP."""
+    import socket
+    import subprocess
+    if not stub:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} asked for, but this box has {have} GPU(s) visible; refusing to run "
+                  f"{n} ranks on fewer devices (a scaling number measured that way would be meaningless)", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FRL_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr, flush=True)
+        return next(rc for _, rc in bad) or 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+def stub_main(args, world: int, rank: int) -> None:
+    """CPU stand-in of the rank body (tests/test_host.py): same launcher, same rendezvous, same fence / MAX-over-ranks
+    timing and all-gather pattern over gloo, with a trivial step instead of the HIP sampler.  Not a measurement."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, A, T = 64, 3, 5
+    x = torch.full((B, A), float(rank))
+    gathered = torch.empty((world * B, A))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = x * 2.0 + 1.0
+        dist.all_gather_into_tensor(gathered, y)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = all(bool((gathered[r * B:(r + 1) * B] == 2.0 * r + 1.0).all()) for r in range(world))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * B * T / (float(tt.item()) / args.steps), "unit": "chain-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub (CPU, gloo): launcher test only",
+                          "gather_ok": ok}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,11 +324,26 @@ def main():
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
+    ap.add_argument("--stub", action="store_true", help="launcher test: CPU / gloo stand-in of the rank body (no GPU, not a measurement)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.stub))      # parent: starts the ranks, touches no GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} in the environment but --gpus {args.gpus}: launch N ranks with --gpus N "
+              f"(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N, or plain python bench.py --gpus N)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if args.stub:
+        stub_main(args, world, rank)
+        return
+    if world > 1 and torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} wants cuda:{local_rank}, but {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr, flush=True)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist

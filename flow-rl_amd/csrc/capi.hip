@@ -80,6 +80,7 @@ static int validate_desc(const FrlDesc* d) {
   if (d->cond_dim < 0) { set_error("cond_dim %d invalid", d->cond_dim); return FRL_EINVAL; }
   if (d->time_embed < FRL_TEMB_NONE || d->time_embed > FRL_TEMB_FOURIER) { set_error("time_embed %d invalid", d->time_embed); return FRL_EINVAL; }
   if (d->time_embed != FRL_TEMB_NONE && (d->time_dim < 4 || (d->time_dim & 1))) { set_error("time_dim %d must be even and >= 4", d->time_dim); return FRL_EINVAL; }
+  if (d->time_embed != FRL_TEMB_NONE && d->time_dim > 4096) { set_error("time_dim %d > 4096 (prepare kernel's LDS rows)", d->time_dim); return FRL_EUNSUPPORTED; }
   if (d->n_hidden < 1 || d->n_hidden > FRL_MAX_HIDDEN) { set_error("n_hidden %d outside [1, %d]", d->n_hidden, FRL_MAX_HIDDEN); return FRL_EINVAL; }
   for (int l = 0; l < d->n_hidden; ++l)
     if (d->hidden[l] < 1) { set_error("hidden[%d] = %d invalid", l, d->hidden[l]); return FRL_EINVAL; }

@@ -72,7 +72,7 @@ __device__ __forceinline__ void pack_edge_layers(const PArgs& a, int tid, int nt
 }
 
 __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
-  extern __shared__ float sh[];  // 3 * NE * Dmax floats
+  extern __shared__ float sh[];  // 3 * Dmax floats: this workgroup's own row of temb, h1, h2
   const Plan& pl = a.plan;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int T = pl.T, H = pl.H, A = pl.A, C = pl.C, D = pl.D, Dp = pl.Dp, AO = pl.AO;
@@ -83,9 +83,9 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
   float* wlp = ws + pl.off_wlp;
   float* wlq = ws + pl.off_wlq;
   float* blp = ws + pl.off_blp;
-  float* temb = sh;                 // [NE][D]
-  float* h1 = sh + (size_t)pl.NE * (D > 0 ? D : 1);
-  float* h2 = h1 + (size_t)pl.NE * (D > 0 ? D : 1);
+  float* temb = sh;                 // [D], row e0 only (indexed by the column d below)
+  float* h1 = sh + (D > 0 ? D : 1);
+  float* h2 = h1 + (D > 0 ? D : 1);
   __shared__ float tvals[256];      // time input of network evaluation e (NE <= 256 checked on host)
 
   const int NE = pl.NE;
@@ -194,30 +194,30 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
         const float two_pi_x = 6.283185307179586f * tvals[j];
         arg = two_pi_x * a.p.time_kernel[dd];
       }
-      temb[idx] = (d < half) ? (float)cos((double)arg) : (float)sin((double)arg);   // cos first
+      temb[d] = (d < half) ? (float)cos((double)arg) : (float)sin((double)arg);   // cos first
     }
     __syncthreads();
     // ---- MLP_0/Dense_0 + mish ---------------------------------------------------------------------
     for (int idx = e0 * D + tid; idx < e1 * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       float acc = 0.0f;
-      for (int k = 0; k < D; ++k) acc = fmaf(temb[j * D + k], a.p.tmlp_kernel[0][(size_t)k * D + d], acc);
-      h1[idx] = mish_exact(acc + a.p.tmlp_bias[0][d]);
+      for (int k = 0; k < D; ++k) acc = fmaf(temb[k], a.p.tmlp_kernel[0][(size_t)k * D + d], acc);
+      h1[d] = mish_exact(acc + a.p.tmlp_bias[0][d]);
     }
     __syncthreads();
     // ---- MLP_0/Dense_1 + mish ---------------------------------------------------------------------
     for (int idx = e0 * D + tid; idx < e1 * D; idx += nt) {
       const int j = idx / D, d = idx - j * D;
       float acc = 0.0f;
-      for (int k = 0; k < D; ++k) acc = fmaf(h1[j * D + k], a.p.tmlp_kernel[1][(size_t)k * D + d], acc);
-      h2[idx] = mish_exact(acc + a.p.tmlp_bias[1][d]);
+      for (int k = 0; k < D; ++k) acc = fmaf(h1[k], a.p.tmlp_kernel[1][(size_t)k * D + d], acc);
+      h2[d] = mish_exact(acc + a.p.tmlp_bias[1][d]);
     }
     __syncthreads();
     // ---- time slice of predictor Dense_0 -> bias table --------------------------------------------
     for (int idx = e0 * H + tid; idx < e1 * H; idx += nt) {
       const int j = idx / H, f = idx - j * H;
       float acc = 0.0f;
-      for (int k = 0; k < D; ++k) acc = fmaf(h2[j * D + k], W0[(size_t)(A + k) * H + f], acc);
+      for (int k = 0; k < D; ++k) acc = fmaf(h2[k], W0[(size_t)(A + k) * H + f], acc);
       tb[idx] = acc + b0[f];
     }
   }
@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(256) frl_prepare_kernel(const PArgs a) {
 
 int launch_prepare(const PArgs& a, hipStream_t stream) {
   const int Dm = a.plan.D > 0 ? a.plan.D : 1;
-  const size_t shbytes = (size_t)3 * a.plan.NE * Dm * sizeof(float);
-  if (shbytes > 60000) { set_error("prepare: T*time_dim too large (%zu B of LDS)", shbytes); return FRL_EUNSUPPORTED; }
+  const size_t shbytes = (size_t)3 * Dm * sizeof(float);   // one row of temb / h1 / h2 per workgroup
+  if (shbytes > 60000) { set_error("prepare: time_dim %d too large (%zu B of LDS)", a.plan.D, shbytes); return FRL_EUNSUPPORTED; }
   hipLaunchKernelGGL(frl_prepare_kernel, dim3(a.plan.NE + 32), dim3(256), shbytes, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }

@@ -33,7 +33,8 @@ def _workspace(nbytes: int, device: torch.device, stream: int = 0) -> torch.Tens
 # descriptor and by (data_ptr, _version) of every parameter and schedule tensor: acting calls between two optimizer
 # steps skip the prepare kernel (55..110 us, a fifth of an acting-sized call).  An entry owns its workspace and keeps
 # its tensors alive, so a data_ptr cannot be recycled while cached; in-place torch updates bump _version and miss.
-# Writes that bypass torch's version counter (a foreign kernel through data_ptr) need cache_prepare=False.
+# Writes that bypass torch's version counter (p.data.copy_/lerp_ EMA updates, a foreign kernel through data_ptr) give a
+# silent stale hit, so the cache is OPT-IN (cache_prepare=True) and clear_prepare_cache() is the explicit invalidation.
 _prep_cache: "collections.OrderedDict" = collections.OrderedDict()
 PREP_CACHE_ENTRIES = 8
 
@@ -111,8 +112,9 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
         d.hidden[i] = int(h)
     d.act = _lib.FRL_ACT[pred.act_name]
     d.clip = 1 if clip_sampler else 0
-    d.x_min = float(x_min) if x_min is not None else 0.0
-    d.x_max = float(x_max) if x_max is not None else 0.0
+    # jnp.clip(x, None, None) leaves a None side unbounded (ddpm.py:200-201, cnf.py:109-110)
+    d.x_min = float(x_min) if x_min is not None else float("-inf")
+    d.x_max = float(x_max) if x_max is not None else float("inf")
     if compute_dtype not in ("f32", "bf16"):
         raise ValueError(f"compute_dtype {compute_dtype!r}: 'f32' (bit-faithful) or 'bf16' (stated-tolerance MFMA variant)")
     d.dtype = _lib.FRL_DTYPE_BF16 if compute_dtype == "bf16" else _lib.FRL_DTYPE_F32
@@ -226,13 +228,16 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
                 compute_dtype: str = "f32", tile_policy: str = "auto", rng_key: Optional[torch.Tensor] = None,
-                rng_impl: Optional[str] = None, cache_prepare: bool = True, rng_shard: Optional[Tuple[int, int]] = None):
+                rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard: Optional[Tuple[int, int]] = None):
     """``rng_shard`` = (first chain, total chains) when this call is one state-shard of a larger batch: the in-kernel
     draws are then the elements of the UNSHARDED normal(key_j, (total, A)), so N ranks reproduce one big call.
     Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored — and, when ``rng_key`` (a (2,)
     uint32 threefry key, flowrl_hip.random) is given, a third element: the rng the reference's sample() returns; the
     per-step noise is then drawn in-kernel unless ``noise`` is passed.  ``compute_dtype`` = "bf16"
-    selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful)."""
+    selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful).
+    ``cache_prepare`` (opt-in) keeps the prepared tables of a call keyed by (data_ptr, _version) of every leaf: only safe
+    when every parameter update goes through torch's version counter (``p.data.copy_()``-style EMA updates and foreign
+    kernels do NOT) — call :func:`clear_prepare_cache` after such an update, or leave it off."""
     lib = _lib.load()
     if not xT.is_cuda:
         raise RuntimeError("flowrl_hip samplers run on the GPU only (xT must be a CUDA/HIP tensor); there is no CPU fallback")

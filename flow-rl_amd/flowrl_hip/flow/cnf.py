@@ -39,7 +39,7 @@ class ContinuousNormalizingFlow:
 
     def sample(self, rng, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                params: Optional[Dict] = None, *, history: bool = False, particles: Optional[int] = None,
-               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None, cache_prepare: bool = True, rng_shard=None):
+               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None):
         """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps.  A (2,) uint32
         threefry key as ``rng`` is advanced as the reference's scan does (cnf.py:126) and returned; anything else is
         returned unchanged."""

@@ -75,7 +75,7 @@ class ContinuousDDPM:
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
                particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None, cache_prepare: bool = True, rng_shard=None):
+               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None):
         """ContinuousDDPM.sample (continuous_ddpm.py:117-222).
         ``rng``: a (2,) uint32 threefry key (flowrl_hip.random.PRNGKey / jax.random.key_data) makes the call a
         true rng-in / rng-out drop-in: the scan's split sequence runs on the GPU, the per-step noise is drawn in-kernel

@@ -67,7 +67,7 @@ class DDPM:
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: str = "ddpm", params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None,
                history: bool = False, particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None, cache_prepare: bool = True, rng_shard=None) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
         """DDPM.sample (ddpm.py:173-221).  Extra keyword-only arguments:
         ``noise`` (T, *xT.shape): the per-iteration N(0, I) draws (iteration j <-> t = T - j);
         ``history``: also return (xt_hist, eps_hist) (ddpm.py:217); ``particles``: chains per condition

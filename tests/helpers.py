@@ -101,13 +101,13 @@ def product_model(c: Case, params, device="cuda"):
                                             x_min=c.x_min, x_max=c.x_max, params=tparams, device=device)
 
 
-def product_run(c: Case, model, xT, cond, noise, device="cuda", history=True):
+def product_run(c: Case, model, xT, cond, noise, device="cuda", history=True, **extra):
     import torch
     x = torch.from_numpy(xT).to(device)
     cd = None if cond is None else torch.from_numpy(cond).to(device)
     nz = torch.from_numpy(noise).to(device)
     kw = dict(history=history, particles=c.particles if c.particles > 1 else None,
-              compute_dtype="bf16" if c.bf16 else "f32", tile_policy=c.tile)
+              compute_dtype="bf16" if c.bf16 else "f32", tile_policy=c.tile, **extra)
     if c.kind == "ddpm":
         _, x0, (xh, eh) = model.sample(None, x, cd, False, c.solver, noise=nz, **kw)
     elif c.kind == "cddpm":

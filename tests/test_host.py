@@ -205,3 +205,39 @@ def test_grad_allreduce_two_ranks_gloo(tmp_path):
     port = 31500 + os.getpid() % 2000
     mp.spawn(_gloo_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+# ---- bench.py launcher: `python bench.py --gpus N` must start N ranks itself ----------------
+def _run_bench(*argv, env_extra=None, timeout=180):
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(root / "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_n_ranks_over_gloo():
+    """The parent starts 2 rank processes (before touching any GPU), they rendezvous on 127.0.0.1 over gloo, run the
+    stub step + all-gather with the bench's fence / MAX-over-ranks timing, and rank 0 prints the ONE JSON line."""
+    import json
+    r = _run_bench("--gpus", "2", "--stub", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["gather_ok"] is True
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() >= 1 else 2
+    r = _run_bench("--gpus", str(max(n, 2)), "--steps", "1", "--warmup", "0")
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = _run_bench("--gpus", "1", "--stub", env_extra={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
