@@ -5,11 +5,37 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "frl_internal.h"
+
+// Workspace of frl_sampler_fwd_static: device memory that exists from module load to process end, one copy per GPU.
+// In host code this name is only a handle for hipGetSymbolAddress; the device address is static_scratch()'s result.
+static __device__ __align__(256) unsigned char scratch[FRL_STATIC_WS_BYTES];
 
 namespace frl {
 
 static thread_local char g_err[512] = "";
+
+// Device address of `scratch` on the CURRENT device, resolved once per device.
+static int static_scratch(void** out) {
+  constexpr int MAXDEV = 64;
+  static std::mutex mu;
+  static void* ptrs[MAXDEV] = {nullptr};
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { set_error("hipGetDevice: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  if (dev < 0 || dev >= MAXDEV) { set_error("device index %d outside [0, %d)", dev, MAXDEV); return FRL_EINVAL; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (ptrs[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) { set_error("hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e)); return FRL_EHIP; }
+    ptrs[dev] = p;
+  }
+  *out = ptrs[dev];
+  return FRL_OK;
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -331,6 +357,29 @@ int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   int rc = frl_sampler_prepare(desc, params, sched, workspace, workspace_bytes, hip_stream);
   if (rc != FRL_OK) return rc;
   return frl_sampler_run(desc, params, bufs, workspace, workspace_bytes, hip_stream);
+}
+
+size_t frl_static_workspace_limit(void) { return (size_t)FRL_STATIC_WS_BYTES; }
+
+int frl_sampler_fwd_static(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                           const FrlFwdBufs* bufs, void* hip_stream) {
+  int rc = validate_desc(desc);
+  if (rc != FRL_OK) return rc;
+  Plan pl;
+  plan_from_desc(*desc, pl);
+  const size_t need = pl.total_floats * sizeof(float);
+  if (need > (size_t)FRL_STATIC_WS_BYTES) {
+    set_error("frl_sampler_fwd_static: this call needs %zu B of scratch, the static buffer holds %zu B (per-state rows of a cond_embedding / "
+              "hoisted condition grow with n_states = %lld): use frl_sampler_fwd with a caller workspace", need, (size_t)FRL_STATIC_WS_BYTES,
+              (long long)desc->n_states);
+    return FRL_EWORKSPACE;
+  }
+  void* ws = nullptr;
+  rc = static_scratch(&ws);
+  if (rc != FRL_OK) return rc;
+  // frl_sampler_prepare rewrites every table and packed image this descriptor reads (padding included), so nothing of the
+  // previous call's contents is consumed; the per-state rows (cfeat, zs) and iteration keys are written by frl_sampler_run.
+  return frl_sampler_fwd(desc, params, sched, bufs, ws, (size_t)FRL_STATIC_WS_BYTES, hip_stream);
 }
 
 static int validate_bwd(const FrlDesc* d) {

@@ -102,6 +102,9 @@ EXPORTS = {
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_sampler_fwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule),
                                   C.POINTER(FrlFwdBufs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_static_workspace_limit": (C.c_size_t, []),
+    "frl_sampler_fwd_static": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule),
+                                         C.POINTER(FrlFwdBufs), C.c_void_p]),
     "frl_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
     "frl_sampler_bwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule), C.POINTER(FrlBwdBufs),
                                   C.c_void_p, C.c_size_t, C.c_void_p]),

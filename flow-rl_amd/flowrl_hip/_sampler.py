@@ -228,7 +228,8 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
                 condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
                 compute_dtype: str = "f32", tile_policy: str = "auto", rng_key: Optional[torch.Tensor] = None,
-                rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard: Optional[Tuple[int, int]] = None):
+                rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard: Optional[Tuple[int, int]] = None,
+                static_scratch: bool = False):
     """``rng_shard`` = (first chain, total chains) when this call is one state-shard of a larger batch: the in-kernel
     draws are then the elements of the UNSHARDED normal(key_j, (total, A)), so N ranks reproduce one big call.
     Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored — and, when ``rng_key`` (a (2,)
@@ -237,8 +238,12 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     selects the bf16-MFMA variant (bf16 operands, f32 accumulate / chain state; stated tolerance, not bit-faithful).
     ``cache_prepare`` (opt-in) keeps the prepared tables of a call keyed by (data_ptr, _version) of every leaf: only safe
     when every parameter update goes through torch's version counter (``p.data.copy_()``-style EMA updates and foreign
-    kernels do NOT) — call :func:`clear_prepare_cache` after such an update, or leave it off."""
+    kernels do NOT) — call :func:`clear_prepare_cache` after such an update, or leave it off.
+    ``static_scratch`` routes the call through ``frl_sampler_fwd_static``: the workspace is the library's file-scope
+    device array (no allocation inside the entry point; calls overlapping on one GPU race; small n_states only)."""
     lib = _lib.load()
+    if static_scratch and cache_prepare:
+        raise ValueError("static_scratch and cache_prepare are exclusive (the static buffer is rewritten by every call)")
     if not xT.is_cuda:
         raise RuntimeError("flowrl_hip samplers run on the GPU only (xT must be a CUDA/HIP tensor); there is no CPU fallback")
     device = xT.device
@@ -278,7 +283,9 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     need = lib.frl_workspace_bytes(C.byref(desc))
     stream = torch.cuda.current_stream(device).cuda_stream
     with torch.cuda.device(device):
-        if cache_prepare:
+        if static_scratch:
+            rc = lib.frl_sampler_fwd_static(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs), stream)
+        elif cache_prepare:
             key = (bytes(desc), device.index, int(stream), tuple((t.data_ptr(), t._version) for t in keep))
             ent = _prep_cache.get(key)
             if ent is None:

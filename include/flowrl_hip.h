@@ -187,6 +187,20 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
                     const FrlFwdBufs* bufs, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* ---- frl_sampler_fwd for callers that cannot allocate ------------------------------------------------------------
+ * No counterpart in the reference: this entry point exists for callers that cannot call hipMalloc — code under HIP
+ * graph capture, tight serving / acting loops, harnesses that forbid allocation.  It is frl_sampler_fwd with the
+ * workspace taken from a file-scope __device__ array of FRL_STATIC_WS_BYTES inside the library (one copy per GPU, held
+ * until the process ends); it calls no hipMalloc / hipFree or any allocating routine.  The caller still passes inputs
+ * and outputs.  A call whose frl_workspace_bytes(desc) exceeds FRL_STATIC_WS_BYTES is refused with FRL_EWORKSPACE (the
+ * per-state rows of a cond_embedding or hoisted condition grow with n_states: ~8000 states at 128 + 256 floats each).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) RACE — serialise
+ * them, or use frl_sampler_fwd with one workspace per stream.  Results are bit-identical to frl_sampler_fwd's. */
+#define FRL_STATIC_WS_BYTES (12u << 20)
+size_t frl_static_workspace_limit(void);
+int frl_sampler_fwd_static(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                           const FrlFwdBufs* bufs, void* hip_stream);
+
 /* ---- chain VJP (DQL-style backprop through the sampler: dql.py:93-123 -> jax.grad through ddpm.py:186-219) ----
  * Given the forward's history xt_hist (want_history = 1) and the cotangent g_x0 = dL/dx0, computes dL/d(params) of the
  * predictor MLP and dL/dxT.  The batch-invariant time branch (O(T * D^2) work) hangs off grad_tb
