@@ -23,7 +23,7 @@ OBJ = CSRC / "_obj"
 OUT = HERE / "flowrl_hip" / "libflowrl_hip.so"
 ARCH = "gfx950"
 # (source, object stem, extra defines); the register-streamed sampler is one translation unit per activation
-SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []), ("sampler_g32.hip", "sampler_g32", []),
+SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []),
            ("cond_embed.hip", "cond_embed", []), ("critic_select.hip", "critic_select", []), ("time_bwd.hip", "time_bwd", []), ("rng.hip", "rng", []), ("sampler_bwd.hip", "sampler_bwd", []),
            ("sampler_bf16.hip", "sampler_bf16", ["-fno-slp-vectorize"]),
            ("sampler_bwd_bf16.hip", "sampler_bwd_bf16", ["-fno-slp-vectorize"])] + \

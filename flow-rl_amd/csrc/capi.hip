@@ -344,10 +344,6 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
     a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
     return launch_sampler_bf16(*desc, a, (hipStream_t)hip_stream);
   }
-  // FRL_SAMPLER=lds selects the LDS K-slab variant (A/B measurements; 256-wide, small x/cond only)
-  static const bool use_lds = [] { const char* e = getenv("FRL_SAMPLER"); return e != nullptr && strcmp(e, "lds") == 0; }();
-  if (use_lds && pl.H == G32_H && pl.AR <= 4 && pl.CK <= 12 && desc->act <= FRL_ACT_RELU && pl.mode <= MODE_CNF_EULER && !pl.hoist && !desc->layer_norm)
-    return launch_sampler_g32(*desc, a, (hipStream_t)hip_stream);
   a.wl_raw = params->kernel[desc->n_hidden];
   return launch_f32_network(a, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
 }

@@ -36,12 +36,6 @@ enum Mode : int {
   MODE_EVAL = 7,           // one plain network evaluation, output = the net's AO outputs (critic scoring, critic.py:178-194)
 };
 
-// FRL_GEO=16 selects the 16x16x4 geometry for 256-wide nets too (A/B measurements)
-inline bool prefer_tr16() {
-  static const bool v = [] { const char* e = getenv("FRL_GEO"); return e != nullptr && e[0] == '1' && e[1] == '6'; }();
-  return v;
-}
-
 // Derived sizes of one call (host + device agree through this one function).
 struct Plan {
   int A, C, D, Dp;      // action dim, cond dim, time_dim, D' (= D or 1) rows of Dense_0 taken by time
@@ -56,9 +50,9 @@ struct Plan {
   int hoist;            // 1: the cond rows of Dense_0 are contracted once per STATE (frl_state_bias_kernel) and enter the
                         //    sampler as a per-state accumulator init: many chains per state, or a cond wider than the budget
   int K0p;              // rows of the packed layer-0 image = XR + KS*CK
-  int merged;           // (LDS-slab kernel only) 1: x rows and cond rows share ONE slab (K0p <= 32)
-  int n_l0;             // (LDS-slab kernel only) layer-0 slabs
-  int NS;               // (LDS-slab kernel only) slabs per step = n_l0 + 8*(L-1) + 1
+  int merged;           // (layout of the packed layer-0 image; was the LDS-slab kernel's) 1: x rows and cond rows share ONE slab (K0p <= 32)
+  int n_l0;             // (layout of the packed layer-0 image; was the LDS-slab kernel's) layer-0 slabs
+  int NS;               // (layout of the packed layer-0 image; was the LDS-slab kernel's) slabs per step = n_l0 + 8*(L-1) + 1
   int mode;
   long long B;
   // workspace layout (float offsets)
@@ -86,7 +80,7 @@ inline int plan_from_desc(const FrlDesc& d, Plan& p) {
 
 // Second half of the plan: geometry and workspace layout from the (possibly overridden) dims above.
 inline int plan_layout(const FrlDesc& d, Plan& p) {
-  p.TR = (p.H <= 256 && !prefer_tr16()) ? 32 : 16;
+  p.TR = (p.H <= 256) ? 32 : 16;
   p.KS = (p.TR == 32) ? 2 : 4;
   p.NR = (p.TR == 32) ? 16 : 4;
   p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
@@ -269,7 +263,6 @@ void set_error(const char* fmt, ...);
 
 // launchers implemented in the .hip files
 int launch_prepare(const PArgs& a, hipStream_t stream);
-int launch_sampler_g32(const FrlDesc& d, const KArgs& a, hipStream_t stream);   // LDS K-slab variant (H = 256 only), A/B reference
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
 template <int ACT> int launch_sampler_lat_act(const KArgs& a, int tile_rows, hipStream_t stream); // latency variant (4 waves per tile), one TU per activation
 // CU count of the current device (cached per thread and device)

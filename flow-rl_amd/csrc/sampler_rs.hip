@@ -30,7 +30,7 @@
 // buffer_load_dwordx4 (per-lane row = the k-slot's feature row, scalar offset = the k-step), a ring of
 // RING k-steps ahead of the MFMAs; they are L2-resident (0.6-3.3 MB) and the four waves of a CU read
 // the same lines at nearly the same time.  There is no LDS weight staging and no barrier in the main
-// loop (the LDS-DMA K-slab variant, sampler_g32.hip, loses ~1.2k cycles per 32 KB slab to DMA issue
+// loop (the LDS-DMA K-slab variant, the round-1 sampler_g32.hip, since removed, lost ~1.2k cycles per 32 KB slab to DMA issue
 // and barrier skew — A/B in DESIGN.md); LDS only holds the small bias / coefficient tables.
 #include "frl_device.h"
 #include "frl_rng.h"
