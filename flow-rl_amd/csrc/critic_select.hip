@@ -55,3 +55,27 @@ int launch_critic_select(const float* q_members, int E, long long n_states, int 
 }
 
 }  // namespace frl
+
+// ---- MFMA lane-map self test (tests only): the operand / accumulator maps every f32 kernel relies on --------------
+namespace frl {
+
+__global__ void __launch_bounds__(64) frl_selftest_mfma32_kernel(const float* A, const float* B, float* D, int K) {
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int k = 0; k < K; k += 2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[li * K + k + lh], B[(k + lh) * 32 + li], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[r];   // row(r, h) of the 32x32 accumulator
+}
+
+int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream) {
+  hipLaunchKernelGGL(frl_selftest_mfma32_kernel, dim3(1), dim3(64), 0, stream, A, B, D, K);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("selftest launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+}  // namespace frl
