@@ -190,23 +190,27 @@ frl_sampler_lat_kernel(const KArgs a) {
       // then the variance about it, each a register sum + lane-group exchange + four per-wave partials through LDS
       // (two extra barriers per layer; the partial buffers alternate, so no third one is needed)
       auto ln_pass = [&](int l) {
-        float s1 = 0.0f;
-        sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; sfor<NR>([&](auto RI) { s1 += acc[jb][decltype(RI)::value]; }); });
+        // every level of these sums is a fixed pairwise tree (four interleaved register partials, the lane-group
+        // butterfly, then the four waves' partials as (w0 + w1) + (w2 + w3)): error growth like numpy's pairwise mean
+        float p1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; p1[(jb * NR + r) & 3] += acc[jb][r]; }); });
+        float s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
 #pragma unroll
         for (int m = TR; m < 64; m <<= 1) s1 += __shfl_xor(s1, m);
         s_stat[wave * TR + li] = s1;
         __syncthreads();
-        const float mean = (s_stat[li] + s_stat[TR + li] + s_stat[2 * TR + li] + s_stat[3 * TR + li]) * (1.0f / H);
-        float s2 = 0.0f;
+        const float mean = ((s_stat[li] + s_stat[TR + li]) + (s_stat[2 * TR + li] + s_stat[3 * TR + li])) * (1.0f / H);
+        float p2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         sfor<NBW>([&](auto JI) {
           constexpr int jb = decltype(JI)::value;
-          sfor<NR>([&](auto RI) { const float v = acc[jb][decltype(RI)::value] - mean; s2 = fmaf(v, v, s2); });
+          sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; const float v = acc[jb][r] - mean; p2[(jb * NR + r) & 3] = fmaf(v, v, p2[(jb * NR + r) & 3]); });
         });
+        float s2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
 #pragma unroll
         for (int m = TR; m < 64; m <<= 1) s2 += __shfl_xor(s2, m);
         s_stat[128 + wave * TR + li] = s2;
         __syncthreads();
-        const float var = (s_stat[128 + li] + s_stat[128 + TR + li] + s_stat[128 + 2 * TR + li] + s_stat[128 + 3 * TR + li]) * (1.0f / H);
+        const float var = ((s_stat[128 + li] + s_stat[128 + TR + li]) + (s_stat[128 + 2 * TR + li] + s_stat[128 + 3 * TR + li])) * (1.0f / H);
         const float rstd = 1.0f / sqrtf(var + 1e-6f);
         const float* sl = s_ln + l * 2 * H + FW * wave;
         sfor<NR>([&](auto RI) {

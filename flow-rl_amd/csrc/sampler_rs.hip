@@ -99,21 +99,25 @@ frl_sampler_rs_kernel(const KArgs a) {
   // Dense -> LayerNorm -> act): mean and E[x^2] over the lane's own registers, combined across the 64 / TR lanes that
   // hold the other feature rows of the same chain; eps = 1e-6.
   auto ln_pass = [&](acc_t (&Q)[NB], const float* sl) {
-    float s1 = 0.0f;
+    // eight interleaved partial sums combined as a tree (then the lane-group butterfly): the rounding error grows with
+    // NB NR / 8 + 3 additions instead of NB NR, i.e. no worse than numpy's pairwise mean
+    float p1[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     sfor<NB>([&](auto BI) {
       constexpr int b = decltype(BI)::value;
-      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; s1 += Q[b][r]; });
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; p1[(b * NR + r) & 7] += Q[b][r]; });
     });
+    float s1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
 #pragma unroll
     for (int m = TR; m < 64; m <<= 1) s1 += __shfl_xor(s1, m);
     const float mean = s1 * (1.0f / H);
     // the variance about the mean (two passes over registers): the same quantity as flax's E[x^2] - E[x]^2 without
     // its float32 cancellation, so the result sits closer to the exact value than the reference's own
-    float s2 = 0.0f;
+    float p2[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     sfor<NB>([&](auto BI) {
       constexpr int b = decltype(BI)::value;
-      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; const float v = Q[b][r] - mean; s2 = fmaf(v, v, s2); });
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; const float v = Q[b][r] - mean; p2[(b * NR + r) & 7] = fmaf(v, v, p2[(b * NR + r) & 7]); });
     });
+    float s2 = ((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p2[4] + p2[5]) + (p2[6] + p2[7]));
 #pragma unroll
     for (int m = TR; m < 64; m <<= 1) s2 += __shfl_xor(s2, m);
     const float rstd = 1.0f / sqrtf(s2 * (1.0f / H) + 1e-6f);

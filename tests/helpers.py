@@ -73,6 +73,43 @@ def oracle_run(c: Case, params, xT, cond, noise, dtype=np.float64):
     return x0, xh, eh
 
 
+def permuted_hidden_units(c: Case, params, seed: int):
+    """The SAME network with the hidden units of every predictor layer renumbered (columns of Dense_l, its bias and
+    LayerNorm rows, rows of Dense_{l+1}): mathematically identical outputs, another float32 summation order."""
+    rng = np.random.default_rng(seed)
+    name = c.spec.predictor_name
+    out = {k: (dict(v) if isinstance(v, dict) else v) for k, v in params.items()}
+    pp = {k: dict(v) for k, v in params[name].items()}
+    L = len(c.hidden)
+    for l in range(L):
+        perm = rng.permutation(c.hidden[l])
+        pp[f"Dense_{l}"]["kernel"] = pp[f"Dense_{l}"]["kernel"][:, perm]
+        pp[f"Dense_{l}"]["bias"] = pp[f"Dense_{l}"]["bias"][perm]
+        if c.ln:
+            pp[f"LayerNorm_{l}"]["scale"] = pp[f"LayerNorm_{l}"]["scale"][perm]
+            pp[f"LayerNorm_{l}"]["bias"] = pp[f"LayerNorm_{l}"]["bias"][perm]
+        pp[f"Dense_{l + 1}"]["kernel"] = pp[f"Dense_{l + 1}"]["kernel"][perm, :]
+    out[name] = pp
+    return out
+
+
+def float32_chain_deviation(c: Case, params, xT, cond, noise, ref, orders: int = 6):
+    """What float32 arithmetic itself can promise on this chain: the largest deviation from the float64 oracle over
+    `orders` float32 evaluations of the same network that differ only in summation order (hidden units renumbered).
+    Returns (max rel err of x0 / xt_hist, rms of the same, max rel err of eps_hist).  An ill-conditioned schedule
+    (cosine: 1/sqrt(alpha_hat_T) = 119) turns one evaluation's 5e-7 rounding noise into a heavy-tailed 1e-5..1e-4 on the
+    worst element, so ONE float32 run is a poor estimate of that bar."""
+    ref0, refx, refe = ref
+    es, rs, ee = 0.0, 0.0, 0.0
+    for k in range(orders):
+        p = params if k == 0 else permuted_hidden_units(c, params, 7000 + k)
+        o = oracle_run(c, p, xT, cond, noise, dtype=np.float32)
+        es = max(es, rel_err(o[0], ref0), rel_err(o[1], refx))
+        rs = max(rs, rms_err(o[0], ref0), rms_err(o[1], refx))
+        ee = max(ee, rel_err(o[2], refe))
+    return es, rs, ee
+
+
 def product_model(c: Case, params, device="cuda"):
     """The flowrl_hip model object for a case (torch tensors on `device`)."""
     import flowrl_hip as fh

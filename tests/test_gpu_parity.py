@@ -2,9 +2,11 @@
 inputs (params, xT, condition, externally supplied noise).
 
 Tolerance (BASELINE.json north_star: "within 1e-5 relative in fp32"), err = |hip - oracle64| / max(|oracle64|, 1):
+  * the first network evaluation (eps_hist[0], no chain feedback):  max err <= 1e-5, rms <= 2 x numpy float32's
   * every network output of every step (eps_hist):  max err <= max(1e-5, 4 * e32)
   * chain state (x0 and every xt_hist row):         max err <= max(1e-5, 4 * e32)  and  rms err <= max(2e-6, 4 * rms32)
-    where e32 / rms32 are the float32 ORACLE's own deviations from the float64 oracle on the same case
+    where e32 / rms32 are the float32 ORACLE's own deviations from the float64 oracle on the same case (on an
+    ill-conditioned chain: the largest over six float32 summation orders, helpers.float32_chain_deviation)
     (1e-5 / 2e-6 are what applies on every BASELINE config; the e32 terms only matter for ill-conditioned
     schedules such as continuous-linear with tmax = 1, where 1/sqrt(alpha_hat_T) = 152).
     The second bound exists because the reverse chain amplifies rounding noise (vp, T=5: x0_hat is
@@ -52,14 +54,23 @@ def _check(case, history=True, slack=4.0):
     assert x0.shape == ref0.shape
     assert np.isfinite(x0).all()
     o32 = H.oracle_run(case, params, xT, cond, noise, dtype=np.float32)
-    tol_state = max(TOL, slack * max(H.rel_err(o32[0], ref0), H.rel_err(o32[1], refx)))
-    tol_rms = max(2e-6, slack * max(H.rms_err(o32[0], ref0), H.rms_err(o32[1], refx)))
-    tol_eps = max(TOL, slack * H.rel_err(o32[2], refe))
+    e32, r32, p32 = max(H.rel_err(o32[0], ref0), H.rel_err(o32[1], refx)), max(H.rms_err(o32[0], ref0), H.rms_err(o32[1], refx)), H.rel_err(o32[2], refe)
+    if slack * e32 > TOL:
+        # ill-conditioned chain: one float32 run is a noisy estimate of what float32 can promise here (the worst element
+        # is heavy-tailed) -> the largest deviation over six float32 summation orders of the same network
+        e32, r32, p32 = H.float32_chain_deviation(case, params, xT, cond, noise, (ref0, refx, refe))
+    tol_state = max(TOL, slack * e32)
+    tol_rms = max(2e-6, slack * r32)
+    tol_eps = max(TOL, slack * p32)
     e0 = H.rel_err(x0, ref0)
     msg = f"{case.name}: x0 rel err {e0:.3e} (state tol {tol_state:.1e})"
     if history:
         ee, ex = H.rel_err(eh, refe), H.rel_err(xh, refx)
-        msg += f", eps_hist {ee:.3e}, xt_hist {ex:.3e}"
+        # the FIRST network evaluation has no chain feedback: the north star's 1e-5 applies to it as it stands, and the
+        # kernel must be as accurate as numpy float32 there (measured: rms 0.9..1.05 x numpy's, every build)
+        e1, r1 = H.rel_err(eh[0], refe[0]), H.rms_err(eh[0], refe[0])
+        msg += f", eps_hist {ee:.3e}, xt_hist {ex:.3e}, first evaluation {e1:.2e} (rms {r1:.2e}, numpy f32 {H.rms_err(o32[2][0], refe[0]):.2e})"
+        assert e1 <= TOL and r1 <= max(1e-6, 2.0 * H.rms_err(o32[2][0], refe[0])), msg
         assert ee <= tol_eps and ex <= tol_state, msg
         assert H.rms_err(xh, refx) <= tol_rms, msg
     print(msg)
@@ -270,9 +281,10 @@ def test_layer_norm_backbones():
         H.Case("ln-dpmpp2m", "cddpm", A=3, S=11, T=6, B=64, temb="learnable_fourier", schedule="cosine", solver="dpm++2m", ln=True, seed=45),
     ]
     # LayerNorm multiplies a layer's rounding noise by rstd * scale; on the ill-conditioned cosine case the float32 numpy
-    # oracle is itself 2.8e-5 from float64 and the latency builds' split sums land at 4.6x that: slack 6 there
+    # oracle is itself 2.8e-5 from float64.  Every build meets the common bar (4 x float32's own deviation): the
+    # LayerNorm sums are fixed pairwise trees at every level (registers, lane groups, waves)
     for c in cases:
-        _check(c, slack=6.0 if TILE.startswith("latency") else 4.0)
+        _check(c, slack=4.0)
     # AUTO on a small batch picks a latency build
     saved = globals()["TILE"]
     globals()["TILE"] = "auto"
