@@ -439,17 +439,9 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   float* ws = (float*)workspace;
   rc = bf16 ? launch_prepare_bwd_bf16(*params, bp16, ws, stream) : launch_prepare_bwd(*params, bp, ws, stream);
   if (rc != FRL_OK) return rc;
-  // gradients are accumulated with float atomics: zero them first
+  // every gradient leaf is WRITTEN once by frl_bwd_reduce_kernel (fixed-order sum of per-workgroup partial tiles in the
+  // workspace): no float atomics, no zero-fill, bitwise reproducible
   const int Dp = pl.Dp;
-  hipError_t e = hipSuccess;
-  for (int l = 0; l <= pl.L && e == hipSuccess; ++l) {
-    const size_t rows = (l == 0) ? (size_t)(pl.A + Dp + pl.C) : (size_t)pl.H;
-    const size_t cols = (l == pl.L) ? (size_t)pl.A : (size_t)pl.H;
-    e = hipMemsetAsync(bufs->grad_kernel[l], 0, rows * cols * sizeof(float), stream);
-    if (l > 0 && e == hipSuccess) e = hipMemsetAsync(bufs->grad_bias[l], 0, cols * sizeof(float), stream);
-  }
-  if (e == hipSuccess) e = hipMemsetAsync(bufs->grad_tb, 0, (size_t)pl.T * pl.H * sizeof(float), stream);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FRL_EHIP; }
 
   BArgs b;
   memset(&b, 0, sizeof(b));
@@ -476,6 +468,8 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   b.grad_tb = bufs->grad_tb;
   b.Dp = Dp;
   b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
+  b.part = ws + (bf16 ? bp16.off_part : bp.off_part);
+  b.n_part = bf16 ? bp16.n_part : bp.n_part;
   rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stream);
   if (rc != FRL_OK) return rc;
   const bool native_time = (desc->time_embed == FRL_TEMB_NONE) ? (bufs->grad_bias[0] != nullptr) : (bufs->grad_tmlp_kernel[0] != nullptr);

@@ -166,8 +166,24 @@ inline size_t time_bwd_scratch_floats(int T, int D) { return 2 * ((size_t)T * (1
 //   Hd = act(z_l)   (input of Dense_{l+1}: the X operand of dW_{l+1})
 //   Ad = act'(z_l)  (re-read by the backward sweep)
 //   Gd = dL/dz_l    (the G operand of dW_l)
+// Deterministic weight-gradient reduction (no float atomics): workgroup w of the dW kernels owns slot w of `part`, a
+// [n_part][dw_part_stride] image of its partial sums — Dense_0 tile [32 staged rows][256], hidden tiles [256][256],
+// Dense_L tile [256][32], bias column sums [L][256] (layers 1..L), per-step dL/dtb [T][256] — and a second kernel
+// (frl_bwd_reduce_kernel) adds the slots in slot order, writing every gradient leaf exactly once.
+struct DwPart {
+  size_t k0, kh, kl, bias, tb, stride;   // float offsets inside one slot; kh is hidden layer 1 (layer l at kh + (l-1) 65536)
+};
+__host__ __device__ inline DwPart dw_part_layout(int L, int T) {
+  DwPart d;
+  d.k0 = 0; d.kh = 8192; d.kl = d.kh + (size_t)(L - 1) * 65536; d.bias = d.kl + 8192; d.tb = d.bias + (size_t)L * 256;
+  d.stride = d.tb + (size_t)T * 256;
+  return d;
+}
+inline int device_cus();
+
 struct BwdPlan {
   Plan f;
+  int n_part; size_t off_part;   // dW partial slots (= workgroups of the dW kernel)
   long long n_wt, n_ts;          // wave tiles (32 chains), tile-steps
   size_t off_wt[FRL_MAX_HIDDEN - 1];   // transposed hidden kernels WT_l[out][in]
   size_t off_wlt;                // transposed, row-padded last kernel  [XR][H]
@@ -193,6 +209,8 @@ inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
   b.off_gd = take((size_t)b.n_ts * p.L * 8192);
   b.off_ge = take((size_t)b.n_ts * 256);
   b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
+  { const long long cus = device_cus(); b.n_part = (int)(b.n_ts < cus ? b.n_ts : cus); if (b.n_part < 1) b.n_part = 1; }
+  b.off_part = take((size_t)b.n_part * dw_part_layout(p.L, p.T).stride);
   b.total_floats = o;
   return 0;
 }
@@ -206,7 +224,9 @@ struct BArgs {
   float* grad_kernel[FRL_MAX_HIDDEN + 1]; float* grad_bias[FRL_MAX_HIDDEN + 1]; float* grad_tb;
   int Dp;                         // time rows of Dense_0 (skipped by the dW_0 scatter)
   long long n_ts;
+  float* part; int n_part;        // dW partial slots (DwPart layout), one per workgroup of the dW kernel
 };
+int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order second stage of the weight-gradient reduction
 
 // ---- backward, bf16-MFMA variant (csrc/sampler_bwd_bf16.hip) -------------------------------------------------
 // Workspace = the forward plan with its bf16 weight stream image, DIRECTLY followed by the backward stream image
@@ -219,6 +239,7 @@ struct BwdPlan16 {
   Plan f;
   long long n_wt, n_ts;
   size_t off_img_b, off_hd, off_ad, off_gd, off_ge, off_tbs, total_floats;
+  int n_part; size_t off_part;
 };
 
 inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
@@ -234,6 +255,8 @@ inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
   b.off_gd = take((size_t)b.n_ts * p.L * 4096);
   b.off_ge = take((size_t)b.n_ts * 256);
   b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
+  { const long long U = ((p.B + 31) / 32) * p.T, cus = device_cus(); b.n_part = (int)(U < cus ? U : cus); if (b.n_part < 1) b.n_part = 1; }
+  b.off_part = take((size_t)b.n_part * dw_part_layout(p.L, p.T).stride);
   b.total_floats = o;
   return 0;
 }

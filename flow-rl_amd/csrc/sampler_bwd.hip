@@ -14,8 +14,11 @@
 //                              and written to the stash; dL/dx_j += W0[x rows] dL/dz_0
 //   frl_bwd_dw_kernel        dW_l = sum over chains and steps of h_{l-1} (x) dL/dz_l: a split-K GEMM whose K is
 //                              the 1.3 M chain-steps — each CU owns a K range and the whole 256 x 256 tile in
-//                              accumulators (256 per lane), operands transposed through LDS, one float-atomic
-//                              flush per layer; bias grads = column sums taken from the same LDS tiles.
+//                              accumulators (256 per lane), operands transposed through LDS; every workgroup writes its
+//                              partial tiles to its own slot of the workspace (plain stores), bias grads = column sums
+//                              taken from the same LDS tiles
+//   frl_bwd_reduce_kernel    adds the slots in slot order and writes every gradient leaf once: no float atomics, so
+//                              two calls on the same inputs give the same bits ("VJP determinism").
 //
 // Weight gradients contract over CHAINS (the lane axis of the sweep), so they cannot be accumulated inside the
 // sweep without 64 K accumulators per wave: the stash (3 x 32 KB per tile-step and layer) is what links the two.
@@ -469,6 +472,12 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
     acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
   float bsum = 0.0f;                                   // column sum of G for feature `tid` (bias gradient)
   int jcur = -1;
+  const DwPart dp = dw_part_layout(L, T);
+  float* slot = b.part + (size_t)blockIdx.x * dp.stride;   // this workgroup's partial sums (deterministic second stage adds the slots)
+  if constexpr (KIND == 0) {
+    // per-step dL/dtb rows: a workgroup's tile-steps cover a few consecutive steps; the other rows of its slot are zero
+    if (tid < 256) for (int j = 0; j < T; ++j) slot[dp.tb + (size_t)j * H + tid] = 0.0f;
+  }
 
   if (KIND == 2) {     // dL/deps fills rows 0..7 (+4 s) of its block: the other rows stay zero in both buffers
     for (int idx = tid; idx < 2 * 32 * LDP; idx += 512) smem[(idx / (32 * LDP)) * 2 * TILE + TILE + idx % (32 * LDP)] = 0.0f;
@@ -543,7 +552,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
       if constexpr (KIND == 0) {
         const int j = (int)(u / n_wt);
         if (j != jcur) {
-          if (jcur >= 0) atomicAdd(&b.grad_tb[jcur * H + tid], bsum);
+          if (jcur >= 0) slot[dp.tb + (size_t)jcur * H + tid] = bsum;    // same thread zero-filled this column above
           bsum = 0.0f; jcur = j;
         }
       }
@@ -569,32 +578,90 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
     __syncthreads();
   }
 
-  // ---- flush: dW_l[in][out] += acc (float atomics, two 128-B row segments per instruction) ----
-  float* gk = b.grad_kernel[lam];
-  const int ncol = (KIND == 2) ? A : H;
+  // ---- flush: this workgroup's partial tile into its slot (plain stores, 128-B row segments; no atomics) ----
+  //   Dense_0: [32 staged rows x | cond][256]   hidden: [256][256]   Dense_L: [256][32]
+  float* pk = slot + (KIND == 0 ? dp.k0 : KIND == 1 ? dp.kh + (size_t)(lam - 1) * 65536 : dp.kl);
+  constexpr int PCOL = (KIND == 2) ? 32 : H;
   sfor<NM>([&](auto MI) {
     constexpr int m = decltype(MI)::value;
     sfor<NN>([&](auto NI) {
       constexpr int n = decltype(NI)::value;
       sfor<16>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
-        int in = 32 * (mb0 + m) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int in = 32 * (mb0 + m) + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int out = 32 * (nb0 + n) + li;
-        bool ok = out < ncol;
-        if constexpr (KIND == 0) {                          // staged rows: x | cond  ->  kernel rows x | (time) | cond
-          ok = ok && in < A + C;
-          if (in >= A) in += b.Dp;
-        }
-        if (ok) atomicAdd(&gk[(size_t)in * ncol + out], acc[m][n][r]);
+        pk[(size_t)in * PCOL + out] = acc[m][n][r];
       });
     });
   });
   if constexpr (KIND == 0) {
-    if (tid < 256 && jcur >= 0) atomicAdd(&b.grad_tb[jcur * H + tid], bsum);
+    if (tid < 256 && jcur >= 0) slot[dp.tb + (size_t)jcur * H + tid] = bsum;
   } else {
-    if (tid < ncol && tid < 256) atomicAdd(&b.grad_bias[lam][tid], bsum);
+    if (tid < 256) slot[dp.bias + (size_t)(lam - 1) * 256 + tid] = (KIND == 2 && tid >= 32) ? 0.0f : bsum;
   }
   __syncthreads();
+}
+
+// ---- second stage: add the slots in slot order, write every leaf once ----------------------------------------------
+// One thread per output element; slot w of every thread's element is one coalesced row of loads.  Four interleaved
+// partial sums combined as a tree: a fixed order, hence bitwise reproducible, and shorter rounding chains than one sum.
+__global__ void __launch_bounds__(256) frl_bwd_reduce_kernel(const BArgs b) {
+  const KArgs& a = b.k;
+  const int A = a.A, C = a.C, T = a.T, L = a.L, Dp = b.Dp, H = 256;
+  const DwPart dp = dw_part_layout(L, T);
+  const long long n0 = (long long)(A + Dp + C) * H, nh = (long long)(L - 1) * 65536, nl = (long long)H * A;
+  const long long nb = (long long)(L - 1) * H + A, ntb = (long long)T * H;
+  const long long total = n0 + nh + nl + nb + ntb;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    float* dst;
+    long long src = -1;          // float offset inside a slot; -1: a structural zero (time rows of Dense_0)
+    long long i = e;
+    if (i < n0) {                // Dense_0 kernel rows x | time | cond  <-  staged rows x | cond
+      const int row = (int)(i / H), col = (int)(i - (long long)row * H);
+      dst = b.grad_kernel[0] + i;
+      if (row < A) src = (long long)dp.k0 + (long long)row * H + col;
+      else if (row >= A + Dp) src = (long long)dp.k0 + (long long)(row - Dp) * H + col;
+    } else if ((i -= n0) < nh) {
+      const int l = 1 + (int)(i >> 16);
+      dst = b.grad_kernel[l] + (i & 65535);
+      src = (long long)dp.kh + i;
+    } else if ((i -= nh) < nl) {
+      const int row = (int)(i / A), col = (int)(i - (long long)row * A);
+      dst = b.grad_kernel[L] + i;
+      src = (long long)dp.kl + (long long)row * 32 + col;
+    } else if ((i -= nl) < nb) {
+      const int l = 1 + (int)(i / H), col = (int)(i - (long long)(l - 1) * H);     // l = L: the A entries of Dense_L's bias
+      dst = b.grad_bias[l] + col;
+      src = (long long)dp.bias + (long long)(l - 1) * 256 + col;
+    } else {
+      i -= nb;
+      dst = b.grad_tb + i;
+      src = (long long)dp.tb + i;
+    }
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (src >= 0) {
+      const float* p = b.part + src;
+      int w = 0;
+      for (; w + 4 <= b.n_part; w += 4) {
+        s0 += p[(size_t)w * dp.stride]; s1 += p[(size_t)(w + 1) * dp.stride];
+        s2 += p[(size_t)(w + 2) * dp.stride]; s3 += p[(size_t)(w + 3) * dp.stride];
+      }
+      if (w < b.n_part) s0 += p[(size_t)w * dp.stride];
+      if (w + 1 < b.n_part) s1 += p[(size_t)(w + 1) * dp.stride];
+      if (w + 2 < b.n_part) s2 += p[(size_t)(w + 2) * dp.stride];
+    }
+    *dst = (s0 + s1) + (s2 + s3);
+  }
+}
+
+int launch_bwd_reduce(const BArgs& b, hipStream_t stream) {
+  const KArgs& a = b.k;
+  const long long total = (long long)(a.A + b.Dp + a.C) * 256 + (long long)(a.L - 1) * 65536 + 256LL * a.A + (long long)(a.L - 1) * 256 + a.A + (long long)a.T * 256;
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(frl_bwd_reduce_kernel, dim3(grid), dim3(256), 0, stream, b);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("bwd reduce launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
 }
 
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -643,14 +710,14 @@ int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
     default: set_error("bwd: activation %d has no VJP kernel (mish / silu / relu)", d.act); return FRL_EUNSUPPORTED;
   }
   if (rc != FRL_OK) return rc;
-  const long long g2 = b.n_ts < ncu ? b.n_ts : ncu;
+  const long long g2 = b.n_part;                        // one partial slot per workgroup (BwdPlan.n_part)
   const size_t lds2 = sizeof(float) * 4 * 256 * 33;     // two (X, G) tile pairs
   hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(frl_bwd_dw_kernel, dim3((int)g2), dim3(512), lds2, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
-  return FRL_OK;
+  return launch_bwd_reduce(b, stream);
 }
 
 }  // namespace frl

@@ -427,6 +427,11 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
     acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
   float bsum = 0.0f;
   int jcur = -1;
+  const DwPart dp = dw_part_layout(L, T);
+  float* slot = b.part + (size_t)blockIdx.x * dp.stride;   // this workgroup's partial sums (frl_bwd_reduce_kernel adds the slots in order)
+  if constexpr (KIND == DW_FIRST) {
+    if (tid < 256) for (int j = 0; j < T; ++j) slot[dp.tb + (size_t)j * H + tid] = 0.0f;
+  }
 
   if (KIND == DW_LAST) {   // dL/deps occupies rows 0..15 of its block: rows 16..31 stay zero in both buffers
     for (int idx = tid; idx < 2 * 32 * DW_ROWB / 4; idx += 512) {
@@ -504,7 +509,7 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
         if constexpr (KIND == DW_FIRST) {
           const int j = (int)(u / n_wtv);
           if (j != jcur) {
-            if (jcur >= 0) atomicAdd(&b.grad_tb[jcur * H + tid], bsum);
+            if (jcur >= 0) slot[dp.tb + (size_t)jcur * H + tid] = bsum;
             bsum = 0.0f; jcur = j;
           }
         }
@@ -534,30 +539,25 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
     __syncthreads();
   }
 
-  // ---- flush ----
-  float* gk = b.grad_kernel[lam];
-  const int ncol = (KIND == DW_LAST) ? A : H;
+  // ---- flush: partial tile into this workgroup's slot (plain stores; the second stage adds the slots in order) ----
+  float* pk = slot + (KIND == DW_FIRST ? dp.k0 : KIND == DW_HIDDEN ? dp.kh + (size_t)(lam - 1) * 65536 : dp.kl);
+  constexpr int PCOL = (KIND == DW_LAST) ? 32 : H;
   sfor<NM>([&](auto MI) {
     constexpr int m = decltype(MI)::value;
     sfor<NN>([&](auto NI) {
       constexpr int n = decltype(NI)::value;
       sfor<16>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
-        int in = 32 * (mb0 + m) + BF_ROWR(r) + 4 * lh;
+        const int in = 32 * (mb0 + m) + BF_ROWR(r) + 4 * lh;
         const int out = 32 * (nb0 + n) + li;
-        bool ok = out < ncol;
-        if constexpr (KIND == DW_FIRST) {                  // staged rows: x | cond  ->  kernel rows x | (time) | cond
-          ok = ok && in < A + C;
-          if (in >= A) in += b.Dp;
-        }
-        if (ok) atomicAdd(&gk[(size_t)in * ncol + out], acc[m][n][r]);
+        pk[(size_t)in * PCOL + out] = acc[m][n][r];
       });
     });
   });
   if constexpr (KIND == DW_FIRST) {
-    if (tid < 256 && jcur >= 0) atomicAdd(&b.grad_tb[jcur * H + tid], bsum);
+    if (tid < 256 && jcur >= 0) slot[dp.tb + (size_t)jcur * H + tid] = bsum;
   } else {
-    if (tid < ncol && tid < 256) atomicAdd(&b.grad_bias[lam][tid], bsum);
+    if (tid < 256) slot[dp.bias + (size_t)(lam - 1) * 256 + tid] = (KIND == DW_LAST && tid >= 32) ? 0.0f : bsum;
   }
   __syncthreads();
 }
@@ -604,15 +604,14 @@ int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& b, hipStream_t stream
     default: set_error("bf16 bwd: activation %d has no VJP kernel (mish / silu / relu)", d.act); return FRL_EUNSUPPORTED;
   }
   if (rc != FRL_OK) return rc;
-  const long long U = ((a.B + 31) / 32) * a.T;
-  const int g2 = (int)(U < ncu ? U : ncu);
+  const int g2 = b.n_part;                                // one partial slot per workgroup (BwdPlan16.n_part)
   const size_t lds2 = 4 * (size_t)DW_TILE;
   hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(frl_bwd_dw_bf16_kernel, dim3(g2), dim3(512), lds2, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
-  return FRL_OK;
+  return launch_bwd_reduce(b, stream);
 }
 
 }  // namespace frl

@@ -96,7 +96,7 @@ def test_cfg5_full_size_vjp(dtype):
       * additivity: grads(full batch) = grads(first half) + grads(second half);
       * linearity: grads(g1 + 2 g2) = grads(g1) + 2 grads(g2);
       * dL/dxT is per chain: a scattered subset's rows, run on their own, reproduce the big run's rows —
-    to float32 summation noise (f32: different split-K ranges and atomic order; bf16: additivity sees the same operand
+    to float32 summation noise (f32: different split-K ranges; bf16: additivity sees the same operand
     roundings in every run, so the same bound, while linearity only holds to the variant's stated tolerance — the
     cotangent-dependent operands dL/dz are rounded to bf16, which is not linear: 1.5e-2 as in test_gpu_vjp_bf16.py).  The per-chain arithmetic itself is pinned against the float64 oracle at small sizes in
     tests/test_gpu_vjp.py / test_gpu_vjp_bf16.py."""
@@ -118,6 +118,12 @@ def test_cfg5_full_size_vjp(dtype):
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
     full, gx_full = run(case, slice(None), g1)
+    # run-to-run determinism: the weight gradients are per-workgroup partial tiles added in slot order by
+    # frl_bwd_reduce_kernel (no float atomics) -> a second call gives the same bits, every leaf
+    again, gx_again = run(case, slice(None), g1)
+    for k in full:
+        assert np.array_equal(full[k], again[k]), f"{k}: VJP not bitwise reproducible"
+    assert np.array_equal(gx_full, gx_again)
     half = dataclasses.replace(case, B=case.B // 2)
     ga, _ = run(half, slice(0, case.B // 2), g1)
     gb, _ = run(half, slice(case.B // 2, None), g1)
