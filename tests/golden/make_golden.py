@@ -18,6 +18,27 @@ sys.path[:0] = [str(ROOT / "oracle"), str(ROOT / "tests")]
 import flowrl_oracle as orc  # noqa: E402
 import helpers as H  # noqa: E402
 
+# Round 2: one fixture per remaining BASELINE geometry.  cfg3's 512x4 parameters are 3.3 MB of random floats, so that
+# file stores the generator seed and a SHA-256 of the parameter bytes instead of the values (a changed generator fails
+# loudly in the test); everything else stays verbatim.
+BIG_CASES = [
+    H.Case("golden_cfg3_fql_512x4", "cnf", A=8, S=39, T=10, B=24, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None, clip=False, seed=105),
+    H.Case("golden_cfg4_dacer_embed", "cddpm", A=17, S=376, T=20, B=4 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
+           cond_embed=True, seed=106),
+]
+VJP_CASE = H.Case("golden_cfg5_vjp", "ddpm", A=3, S=11, T=5, B=40, seed=107)
+CRITIC = dict(name="golden_critic_select", B=12, N=10, S=11, A=3, hidden=(256, 256, 256), act="mish", E=2, seed=108)
+
+
+def params_digest(params):
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in sorted(orc.flatten_tree(params).items()):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v, dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
 CASES = [
     H.Case("golden_cfg1_toy2d", "ddpm", A=2, S=1, T=20, B=48, schedule="linear", clip=False, x_min=-4.0, x_max=4.0, seed=101),
     H.Case("golden_cfg2_hopper", "ddpm", A=3, S=11, T=5, B=48, seed=102),
@@ -36,6 +57,37 @@ def main():
         flat = {"p:" + k: v for k, v in orc.flatten_tree(params).items()}
         np.savez_compressed(out / f"{c.name}.npz", xT=xT, cond=cond, noise=noise, x0=x0, xt_hist=xh, eps_hist=eh, **flat)
         print(c.name, x0.shape, float(np.abs(x0).max()))
+    for c in BIG_CASES:
+        params, xT, cond, noise = H.make_inputs(c)
+        x0, xh, eh = H.oracle_run(c, params, xT, cond, noise, dtype=np.float64)
+        keep = dict(xT=xT, cond=cond, noise=noise, x0=x0, xt_hist=xh, eps_hist=eh)
+        if c.hidden[0] == 512:
+            keep.update(params_sha256=np.array(params_digest(params)), params_seed=np.array(c.seed))
+        else:
+            keep.update({"p:" + k: v for k, v in orc.flatten_tree(params).items()})
+        np.savez_compressed(out / f"{c.name}.npz", **keep)
+        print(c.name, x0.shape, float(np.abs(x0).max()))
+    # chain VJP (cfg5 shapes): cotangent in, every gradient leaf + dL/dxT out (float64 manual-backprop oracle)
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_gpu_vjp import oracle_vjp, _flatten
+    c = VJP_CASE
+    params, xT, cond, noise = H.make_inputs(c)
+    g = np.random.default_rng(77 + c.seed).standard_normal((c.B, c.A)).astype(np.float32)
+    x0, gref, gx = oracle_vjp(c, params, xT, cond, noise, g)
+    np.savez_compressed(out / f"{c.name}.npz", xT=xT, cond=cond, noise=noise, g=g, x0=x0, g_xT=gx,
+                        **{"p:" + k: v for k, v in orc.flatten_tree(params).items()},
+                        **{"g:" + k: v for k, v in _flatten(gref).items()})
+    print(c.name, len(_flatten(gref)), "leaves")
+    # critic scoring + best-of-N (dql.py:151-161): q = min over the ensemble, argmax index, chosen action
+    k = CRITIC
+    rng = np.random.default_rng(k["seed"])
+    cp = orc.make_critic_params(k["S"], k["A"], k["hidden"], k["E"], k["seed"])
+    obs = rng.standard_normal((k["B"], k["S"])).astype(np.float32)
+    actions = np.clip(rng.standard_normal((k["B"], k["N"], k["A"])), -1, 1).astype(np.float32)
+    best, idx, q = orc.select_best(orc.cast_tree(cp, np.float64), obs.astype(np.float64), actions.astype(np.float64), len(k["hidden"]), k["act"])
+    np.savez_compressed(out / f"{k['name']}.npz", obs=obs, actions=actions, q=q, idx=idx, best=best,
+                        **{"p:" + n: v for n, v in orc.flatten_tree(cp).items()})
+    print(k["name"], q.shape)
 
 
 if __name__ == "__main__":

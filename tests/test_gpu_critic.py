@@ -59,6 +59,25 @@ def test_critic_select(cfg):
     _run(**cfg)
 
 
+def test_critic_select_against_committed_golden():
+    """frl_critic_select against tests/golden/golden_critic_select.npz: no oracle run."""
+    from pathlib import Path
+    import torch
+    import flowrl_hip as fh
+    z = np.load(Path(__file__).resolve().parent / "golden" / "golden_critic_select.npz")
+    cp = orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    critic = fh.Ensemblize(base=fh.ScalarCritic(backbone=fh.MLP(hidden_dims=[256, 256, 256], activation="mish")), ensemble_size=2)
+    best, idx, q = fh.critic_select(critic, fh.tree_from_numpy(cp, "cuda"), torch.from_numpy(z["obs"]).cuda(),
+                                    torch.from_numpy(z["actions"]).cuda(), z["actions"].shape[1], temperature=0.0)
+    torch.cuda.synchronize()
+    q, idx, best = q.cpu().numpy(), idx.cpu().numpy(), best.cpu().numpy()
+    assert np.max(np.abs(q - z["q"]) / np.maximum(np.abs(z["q"]), 1.0)) <= 1e-5
+    srt = np.sort(z["q"], axis=-1)
+    clear = (srt[:, -1] - srt[:, -2]) > 4e-5 * max(np.abs(z["q"]).max(), 1.0)
+    assert (idx[clear] == z["idx"][clear]).all()
+    np.testing.assert_array_equal(best, z["actions"][np.arange(len(idx)), idx])
+
+
 def test_sample_and_select_end_to_end():
     """jit_sample_and_select (dql.py:130-162): sampler (particles broadcast) -> critic -> argmax, against the oracle chain."""
     import torch

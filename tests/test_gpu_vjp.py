@@ -143,3 +143,24 @@ def test_vjp_is_bitwise_reproducible(dtype):
         for k, v in runs[0][0].items():
             assert np.array_equal(v, other[0][k]), f"{k} differs between two identical calls"
         assert np.array_equal(runs[0][1], other[1])
+
+
+def test_vjp_against_committed_golden():
+    """The product VJP against tests/golden/golden_cfg5_vjp.npz (every gradient leaf + dL/dxT): no oracle run."""
+    from pathlib import Path
+    import torch
+    import flowrl_oracle as orc
+    z = np.load(Path(__file__).resolve().parent / "golden" / "golden_cfg5_vjp.npz")
+    case = H.Case("golden_cfg5_vjp", "ddpm", A=3, S=11, T=5, B=40, seed=107)
+    params = orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    model = H.product_model(case, params)
+    grads, gxT, _ = product_vjp(case, model, z["xT"], z["cond"], z["noise"], z["g"])
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in _flatten(grads).items()}
+    want = {k[2:]: z[k] for k in z.files if k.startswith("g:")}
+    assert set(got) == set(want)
+    got["dL/dxT"], want["dL/dxT"] = gxT.cpu().numpy(), z["g_xT"]
+    for k, r in want.items():
+        d = got[k].astype(np.float64) - r
+        scale = max(np.abs(r).max(), 1e-30)
+        assert np.abs(d).max() / scale <= TOL_MAX and np.sqrt(np.mean(d * d)) / scale <= TOL_RMS, k

@@ -309,6 +309,47 @@ def test_oracle_reproduces_golden(case):
     assert H.rel_err(r32[0], z["x0"]) < 2e-5
 
 
+def _golden_params(z, case):
+    """Parameters of a golden file: stored verbatim ("p:" entries), or — cfg3's 3.3 MB of 512-wide kernels — regenerated
+    from the stored seed and checked against the stored SHA-256 of their bytes."""
+    import hashlib
+    if "params_sha256" not in z.files:
+        return orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    assert int(z["params_seed"]) == case.seed
+    params = orc.make_params(case.spec, case.S, seed=case.seed, cond_in_dim=case.S)
+    h = hashlib.sha256()
+    for k, v in sorted(orc.flatten_tree(params).items()):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v, dtype=np.float32).tobytes())
+    assert h.hexdigest() == str(z["params_sha256"]), "the parameter generator changed: regenerate tests/golden"
+    return params
+
+
+GOLDEN_R2 = [
+    H.Case("golden_cfg3_fql_512x4", "cnf", A=8, S=39, T=10, B=24, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None, clip=False, seed=105),
+    H.Case("golden_cfg4_dacer_embed", "cddpm", A=17, S=376, T=20, B=4 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
+           cond_embed=True, seed=106),
+]
+
+
+@pytest.mark.parametrize("case", GOLDEN_R2, ids=lambda c: c.name)
+def test_oracle_reproduces_golden_r2(case):
+    z = np.load(GOLD / f"{case.name}.npz")
+    params = _golden_params(z, case)
+    x0, xh, eh = H.oracle_run(case, params, z["xT"], z["cond"], z["noise"], np.float64)
+    np.testing.assert_allclose(x0, z["x0"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(xh, z["xt_hist"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(eh, z["eps_hist"], rtol=1e-11, atol=1e-13)
+
+
+def test_oracle_reproduces_golden_critic():
+    z = np.load(GOLD / "golden_critic_select.npz")
+    cp = orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    best, idx, q = orc.select_best(orc.cast_tree(cp, np.float64), z["obs"].astype(np.float64), z["actions"].astype(np.float64), 3, "mish")
+    np.testing.assert_allclose(q, z["q"], rtol=1e-11, atol=1e-13)
+    assert np.array_equal(idx, z["idx"]) and np.array_equal(best, z["best"])
+
+
 def test_bf16_round_matches_torch():
     import torch
     rng = np.random.default_rng(0)

@@ -128,3 +128,24 @@ def test_vjp_other_samplers_match_finite_differences(kind, solver, clip):
     xm[1, 2] -= h
     fd = (float(np.sum(g * fwd(params, xp))) - float(np.sum(g * fwd(params, xm)))) / (2 * h)
     assert abs(fd - gx[1, 2]) <= tol * max(1.0, abs(fd))
+
+
+def test_vjp_oracle_reproduces_golden():
+    """tests/golden/golden_cfg5_vjp.npz (made by tests/golden/make_golden.py): pins the manual-backprop oracle."""
+    from pathlib import Path
+    import flowrl_oracle as orc
+    import flowrl_oracle_vjp as ov
+    import helpers as H
+    z = np.load(Path(__file__).resolve().parent / "golden" / "golden_cfg5_vjp.npz")
+    case = H.Case("golden_cfg5_vjp", "ddpm", A=3, S=11, T=5, B=40, seed=107)
+    params = orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    tables = orc.ddpm_tables(case.T, case.schedule, dtype=np.float32)
+    x0, grads, gx = ov.ddpm_sample_vjp(case.spec, params, tables, z["xT"], z["cond"], z["noise"], z["g"], solver="ddpm",
+                                       steps=case.T, clip_sampler=True, x_min=-1.0, x_max=1.0)
+    np.testing.assert_allclose(x0, z["x0"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(gx, z["g_xT"], rtol=1e-9, atol=1e-12)
+    flat = orc.flatten_tree(grads)
+    want = {k[2:]: z[k] for k in z.files if k.startswith("g:")}
+    assert set(flat) == set(want)
+    for k in want:
+        np.testing.assert_allclose(flat[k], want[k], rtol=1e-9, atol=1e-12, err_msg=k)
