@@ -1,89 +1,218 @@
-// XLA-FFI (jax.ffi) registration shim: a thin translation of an XLA custom call onto the plain C ABI
-// (include/flowrl_hip.h).  NOT compiled by build.py in this container: jaxlib's headers
-// (xla/ffi/api/ffi.h, found via jax.ffi.include_dir()) are absent here and cannot be fetched, so this
-// file has never been compile-checked — INTEGRATION.md says how a maintainer builds it:
+// XLA-FFI (jax.ffi) registration shim: a thin translation of XLA custom calls onto the plain C ABI
+// (include/flowrl_hip.h).  Handlers: FrlSamplerFwd (noise-tensor or keyed rng-in / rng-out form) and FrlSamplerBwd.
+//
+// NOT compiled by build.py in this container: jaxlib's headers (xla/ffi/api/ffi.h, found via jax.ffi.include_dir())
+// are absent here and cannot be fetched.  What IS checked here: tests/test_abi.py::test_ffi_shim_compile_smoke runs
+// `g++ -fsyntax-only` on this file against tests/ffi_stub/xla/ffi/api/ffi.h — a minimal in-tree declaration of the
+// handful of xla::ffi names used below, a COMPILE SMOKE ONLY (names, arity, types), not jaxlib's header.  A maintainer
+// builds the real thing as INTEGRATION.md says:
 //
 //   hipcc -std=c++17 -fPIC -shared -I$(python -c "import jax; print(jax.ffi.include_dir())") \
 //         -Iinclude flow-rl_amd/csrc/xla_ffi_shim.cc -Lflow-rl_amd/flowrl_hip -lflowrl_hip -o libflowrl_hip_ffi.so
 //
-// Operands (all F32, device): xT, cond, noise, betas, alphas, alpha_hats, postvars, ts, time_kernel,
-// tmlp_k0, tmlp_b0, tmlp_k1, tmlp_b1, then (kernel_i, bias_i) for i = 0..L as remaining args.
-// Results: x0 [, xt_hist, eps_hist].  Attrs mirror FrlDesc (the jit static_argnames).
+// The xla::ffi surface is kept small on purpose: every operand / result arrives through RemainingArgs / RemainingRets
+// as AnyBuffer in a FIXED order, every static through one attribute Dictionary (missing optional attributes take the
+// defaults below), so the binding is the same whatever the layer count or the optional pieces.
+//
+// FrlSamplerFwd operands (a 0-element buffer = "absent"):
+//    0 xT (B, A) f32          1 cond (n_states, C | cond_in_dim) f32
+//    2 noise (T, B, A) f32   -- or, with attr rng_impl != 0, the raw threefry key (2,) u32 (jax.random.key_data)
+//    3..10 betas, alphas, alpha_hats, postvars, ts, mid_ts, mid_alphas, mid_sigmas   (FrlSchedule)
+//   11 time_embedding/kernel     12..15 MLP_0/Dense_{0,1} kernel, bias
+//   16..19 cond_embedding/Dense_{0,1} kernel, bias (attr cond_embed = 1)
+//   20.. (kernel_i, bias_i) for i = 0..L, then with attr layer_norm = 1 (scale_i, bias_i) for i = 0..L-1
+// results: x0 (B, A); then rng_out (2,) u32 when rng_impl != 0; then xt_hist, eps_hist (T, B, A) when want_history = 1.
+//
+// FrlSamplerBwd operands: 0 xt_hist, 1 cond, 2 g_x0, 3..19 as above, 20.. (kernel_i, bias_i) for i = 0..L.
+// results: g_xT (B, A); (grad_kernel_i, grad_bias_i) for i = 0..L; grad_tb (T, H); then, with attr native_time = 1,
+//          grad MLP_0/Dense_{0,1} kernel, bias and grad time_embedding/kernel (FrlBwdBufs' optional outputs).
 #include <cstdint>
 #include <cstring>
+
+#include <hip/hip_runtime_api.h>
 
 #include "flowrl_hip.h"
 #include "xla/ffi/api/ffi.h"
 
 namespace ffi = xla::ffi;
 
-static ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch,
-                                    ffi::Buffer<ffi::F32> xT, ffi::Buffer<ffi::F32> cond, ffi::Buffer<ffi::F32> noise,
-                                    ffi::Buffer<ffi::F32> betas, ffi::Buffer<ffi::F32> alphas,
-                                    ffi::Buffer<ffi::F32> alpha_hats, ffi::Buffer<ffi::F32> postvars,
-                                    ffi::Buffer<ffi::F32> ts, ffi::Buffer<ffi::F32> time_kernel,
-                                    ffi::Buffer<ffi::F32> tk0, ffi::Buffer<ffi::F32> tb0,
-                                    ffi::Buffer<ffi::F32> tk1, ffi::Buffer<ffi::F32> tb1,
-                                    ffi::RemainingArgs layers, ffi::Result<ffi::Buffer<ffi::F32>> x0,
-                                    ffi::RemainingRets hist, int32_t kind, int32_t solver, int32_t steps,
-                                    int64_t n_states, int32_t particles, int32_t time_embed, int32_t time_dim,
-                                    int32_t act, int32_t clip, float x_min, float x_max) {
-  FrlDesc d;
-  std::memset(&d, 0, sizeof(d));
-  d.abi_version = FRL_ABI_VERSION;
-  d.kind = kind; d.solver = solver; d.steps = steps; d.n_states = n_states; d.particles = particles;
-  d.x_dim = (int32_t)xT.dimensions().back();
-  d.cond_dim = cond.element_count() ? (int32_t)cond.dimensions().back() : 0;
-  d.time_embed = time_embed; d.time_dim = time_dim;
-  d.n_hidden = (int32_t)layers.size() / 2 - 1;
-  if (d.n_hidden < 1 || d.n_hidden > FRL_MAX_HIDDEN) return ffi::Error(ffi::ErrorCode::kInvalidArgument, "bad layer count");
-  FrlParams p;
-  std::memset(&p, 0, sizeof(p));
-  for (int l = 0; l <= d.n_hidden; ++l) {
-    auto k = layers.get<ffi::Buffer<ffi::F32>>(2 * l);
-    auto b = layers.get<ffi::Buffer<ffi::F32>>(2 * l + 1);
-    if (!k.has_value() || !b.has_value()) return ffi::Error(ffi::ErrorCode::kInvalidArgument, "layer operands must be f32");
-    p.kernel[l] = k->typed_data(); p.bias[l] = b->typed_data();
-    if (l < d.n_hidden) d.hidden[l] = (int32_t)k->dimensions().back();
+namespace {
+
+constexpr int kFixedOperands = 20;
+
+ffi::Error Invalid(const char* msg) { return ffi::Error(ffi::ErrorCode::kInvalidArgument, msg); }
+
+ffi::Error FromRc(int rc) {
+  if (rc == FRL_OK) return ffi::Error::Success();
+  return ffi::Error(rc == FRL_EUNSUPPORTED ? ffi::ErrorCode::kUnimplemented
+                    : rc == FRL_EWORKSPACE ? ffi::ErrorCode::kResourceExhausted
+                                           : ffi::ErrorCode::kInvalidArgument,
+                    frl_last_error());
+}
+
+template <typename T>
+T AttrOr(const ffi::Dictionary& attrs, const char* name, T fallback) {
+  auto v = attrs.get<T>(name);
+  return v.has_value() ? *v : fallback;
+}
+
+// operand i as a device pointer of the expected element type; nullptr when it has no elements
+template <typename T>
+bool Operand(const ffi::RemainingArgs& args, size_t i, ffi::DataType want, const T** out, int64_t* last_dim = nullptr) {
+  auto b = args.get<ffi::AnyBuffer>(i);
+  if (!b.has_value() || (b->element_count() != 0 && b->element_type() != want)) return false;
+  *out = b->element_count() ? static_cast<const T*>(b->untyped_data()) : nullptr;
+  if (last_dim != nullptr) *last_dim = b->dimensions().size() ? b->dimensions().back() : 0;
+  return true;
+}
+
+template <typename T>
+bool Output(const ffi::RemainingRets& rets, size_t i, ffi::DataType want, T** out) {
+  auto b = rets.get<ffi::AnyBuffer>(i);
+  if (!b.has_value() || (*b)->element_type() != want) return false;
+  *out = static_cast<T*>((*b)->untyped_data());
+  return true;
+}
+
+// FrlDesc from the attribute dictionary + operand shapes; FrlParams / FrlSchedule from operands 3.. (shared by both handlers)
+ffi::Error Marshal(const ffi::RemainingArgs& args, const ffi::Dictionary& attrs, int64_t x_dim, int64_t cond_last,
+                   FrlDesc* d, FrlParams* p, FrlSchedule* s) {
+  std::memset(d, 0, sizeof(*d));
+  std::memset(p, 0, sizeof(*p));
+  std::memset(s, 0, sizeof(*s));
+  d->abi_version = FRL_ABI_VERSION;
+  d->kind = AttrOr<int32_t>(attrs, "kind", FRL_KIND_DDPM);
+  d->solver = AttrOr<int32_t>(attrs, "solver", FRL_SOLVER_DDPM);
+  d->steps = AttrOr<int32_t>(attrs, "steps", 0);
+  d->n_states = AttrOr<int64_t>(attrs, "n_states", 0);
+  d->particles = AttrOr<int32_t>(attrs, "particles", 1);
+  d->x_dim = (int32_t)x_dim;
+  d->time_embed = AttrOr<int32_t>(attrs, "time_embed", FRL_TEMB_POSITIONAL);
+  d->time_dim = AttrOr<int32_t>(attrs, "time_dim", 64);
+  d->act = AttrOr<int32_t>(attrs, "act", FRL_ACT_MISH);
+  d->clip = AttrOr<int32_t>(attrs, "clip", 0);
+  d->x_min = AttrOr<float>(attrs, "x_min", 0.0f);
+  d->x_max = AttrOr<float>(attrs, "x_max", 0.0f);
+  d->dtype = AttrOr<int32_t>(attrs, "dtype", FRL_DTYPE_F32);
+  d->want_history = AttrOr<int32_t>(attrs, "want_history", 0);
+  d->cond_embed = AttrOr<int32_t>(attrs, "cond_embed", 0);
+  d->tile_policy = AttrOr<int32_t>(attrs, "tile_policy", FRL_TILE_AUTO);
+  d->rng_impl = AttrOr<int32_t>(attrs, "rng_impl", FRL_RNG_NONE);
+  d->layer_norm = AttrOr<int32_t>(attrs, "layer_norm", 0);
+  if (d->cond_embed) { d->cond_in_dim = (int32_t)cond_last; d->cond_dim = 128; }
+  else d->cond_dim = (int32_t)cond_last;
+
+  const float** sched[8] = {&s->betas, &s->alphas, &s->alpha_hats, &s->postvars, &s->ts, &s->mid_ts, &s->mid_alphas, &s->mid_sigmas};
+  for (int i = 0; i < 8; ++i)
+    if (!Operand<float>(args, 3 + i, ffi::DataType::F32, sched[i])) return Invalid("schedule operands (3..10) must be f32");
+  bool ok = Operand<float>(args, 11, ffi::DataType::F32, &p->time_kernel);
+  for (int k = 0; k < 2 && ok; ++k) {
+    ok = Operand<float>(args, 12 + 2 * k, ffi::DataType::F32, &p->tmlp_kernel[k]) &&
+         Operand<float>(args, 13 + 2 * k, ffi::DataType::F32, &p->tmlp_bias[k]) &&
+         Operand<float>(args, 16 + 2 * k, ffi::DataType::F32, &p->cond_kernel[k]) &&
+         Operand<float>(args, 17 + 2 * k, ffi::DataType::F32, &p->cond_bias[k]);
   }
-  p.time_kernel = time_kernel.element_count() ? time_kernel.typed_data() : nullptr;
-  p.tmlp_kernel[0] = tk0.typed_data(); p.tmlp_bias[0] = tb0.typed_data();
-  p.tmlp_kernel[1] = tk1.typed_data(); p.tmlp_bias[1] = tb1.typed_data();
-  d.act = act; d.clip = clip; d.x_min = x_min; d.x_max = x_max; d.dtype = FRL_DTYPE_F32;
-  d.want_history = hist.size() == 2 ? 1 : 0;
-  FrlSchedule s = {betas.typed_data(), alphas.typed_data(), alpha_hats.typed_data(), postvars.typed_data(),
-                   ts.element_count() ? ts.typed_data() : nullptr};
-  FrlFwdBufs b;
-  std::memset(&b, 0, sizeof(b));
-  b.xT = xT.typed_data();
-  b.cond = d.cond_dim ? cond.typed_data() : nullptr;
-  b.noise = noise.element_count() ? noise.typed_data() : nullptr;
-  b.x0 = x0->typed_data();
-  if (d.want_history) {
-    b.xt_hist = hist.get<ffi::Buffer<ffi::F32>>(0).value()->typed_data();
-    b.eps_hist = hist.get<ffi::Buffer<ffi::F32>>(1).value()->typed_data();
+  if (!ok) return Invalid("time / cond-embedding operands (11..19) must be f32");
+
+  const size_t rest = args.size() - kFixedOperands;
+  const size_t per_hidden = d->layer_norm ? 4 : 2;            // (kernel, bias) [+ (ln scale, ln bias)] per hidden layer
+  if (args.size() < kFixedOperands + 4 || (rest - 2) % per_hidden != 0) return Invalid("layer operands: (kernel_i, bias_i) for i = 0..L [+ LayerNorm rows]");
+  d->n_hidden = (int32_t)((rest - 2) / per_hidden);
+  if (d->n_hidden < 1 || d->n_hidden > FRL_MAX_HIDDEN) return Invalid("hidden layer count outside [1, FRL_MAX_HIDDEN]");
+  for (int l = 0; l <= d->n_hidden; ++l) {
+    int64_t width = 0;
+    if (!Operand<float>(args, kFixedOperands + 2 * l, ffi::DataType::F32, &p->kernel[l], &width) ||
+        !Operand<float>(args, kFixedOperands + 2 * l + 1, ffi::DataType::F32, &p->bias[l]))
+      return Invalid("layer operands must be f32");
+    if (l < d->n_hidden) d->hidden[l] = (int32_t)width;
   }
-  const size_t need = frl_workspace_bytes(&d);
-  if (need == 0) return ffi::Error(ffi::ErrorCode::kInvalidArgument, frl_last_error());
-  auto ws = scratch.Allocate(need, 256);
-  if (!ws.has_value()) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "scratch allocation failed");
-  const int rc = frl_sampler_fwd(&d, &p, &s, &b, *ws, need, (void*)stream);
-  if (rc != FRL_OK) return ffi::Error(rc == FRL_EUNSUPPORTED ? ffi::ErrorCode::kUnimplemented : ffi::ErrorCode::kInvalidArgument, frl_last_error());
+  if (d->layer_norm) {
+    const size_t base = kFixedOperands + 2 * (size_t)(d->n_hidden + 1);
+    for (int l = 0; l < d->n_hidden; ++l)
+      if (!Operand<float>(args, base + 2 * l, ffi::DataType::F32, &p->ln_scale[l]) ||
+          !Operand<float>(args, base + 2 * l + 1, ffi::DataType::F32, &p->ln_bias[l]))
+        return Invalid("LayerNorm operands must be f32");
+  }
   return ffi::Error::Success();
 }
 
-XLA_FFI_DEFINE_HANDLER_SYMBOL(
-    FrlSamplerFwd, FrlSamplerFwdImpl,
-    ffi::Ffi::Bind()
-        .Ctx<ffi::PlatformStream<hipStream_t>>()
-        .Ctx<ffi::ScratchAllocator>()
-        .Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>()   // xT cond noise
-        .Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>()   // betas alphas alpha_hats
-        .Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>()   // postvars ts time_kernel
-        .Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>().Arg<ffi::Buffer<ffi::F32>>()
-        .RemainingArgs()
-        .Ret<ffi::Buffer<ffi::F32>>()
-        .RemainingRets()
-        .Attr<int32_t>("kind").Attr<int32_t>("solver").Attr<int32_t>("steps").Attr<int64_t>("n_states")
-        .Attr<int32_t>("particles").Attr<int32_t>("time_embed").Attr<int32_t>("time_dim").Attr<int32_t>("act")
-        .Attr<int32_t>("clip").Attr<float>("x_min").Attr<float>("x_max"));
+ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
+                             ffi::RemainingRets rets, ffi::Dictionary attrs) {
+  if (args.size() < kFixedOperands + 4) return Invalid("FrlSamplerFwd: too few operands");
+  FrlDesc d; FrlParams p; FrlSchedule s;
+  FrlFwdBufs b;
+  std::memset(&b, 0, sizeof(b));
+  int64_t x_dim = 0, cond_last = 0;
+  if (!Operand<float>(args, 0, ffi::DataType::F32, &b.xT, &x_dim) || !Operand<float>(args, 1, ffi::DataType::F32, &b.cond, &cond_last))
+    return Invalid("xT / cond must be f32");
+  if (b.cond == nullptr) cond_last = 0;
+  if (ffi::Error e = Marshal(args, attrs, x_dim, cond_last, &d, &p, &s); e.failure()) return e;
+  size_t out = 0;
+  if (!Output<float>(rets, out++, ffi::DataType::F32, &b.x0)) return Invalid("result 0 (x0) must be f32");
+  if (d.rng_impl != FRL_RNG_NONE) {          // keyed form: operand 2 is the threefry key, result 1 the advanced key
+    if (!Operand<uint32_t>(args, 2, ffi::DataType::U32, &b.rng_key) || !Output<uint32_t>(rets, out++, ffi::DataType::U32, &b.rng_out))
+      return Invalid("rng_impl != 0: operand 2 = key (2,) u32, result 1 = rng_out (2,) u32");
+  } else if (!Operand<float>(args, 2, ffi::DataType::F32, &b.noise)) {
+    return Invalid("noise must be f32");
+  }
+  if (d.want_history && (!Output<float>(rets, out, ffi::DataType::F32, &b.xt_hist) || !Output<float>(rets, out + 1, ffi::DataType::F32, &b.eps_hist)))
+    return Invalid("want_history = 1: results xt_hist, eps_hist (T, B, A) f32");
+  if (frl_validate(&d) != FRL_OK) return FromRc(frl_validate(&d));
+  const size_t need = frl_workspace_bytes(&d);
+  auto ws = scratch.Allocate(need > 0 ? need : 256, 256);
+  if (!ws.has_value()) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "scratch allocation failed");
+  return FromRc(frl_sampler_fwd(&d, &p, &s, &b, *ws, need, (void*)stream));
+}
+
+ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
+                             ffi::RemainingRets rets, ffi::Dictionary attrs) {
+  if (args.size() < kFixedOperands + 4) return Invalid("FrlSamplerBwd: too few operands");
+  FrlDesc d; FrlParams p; FrlSchedule s;
+  FrlBwdBufs b;
+  std::memset(&b, 0, sizeof(b));
+  int64_t x_dim = 0, cond_last = 0, unused = 0;
+  if (!Operand<float>(args, 0, ffi::DataType::F32, &b.xt_hist, &unused) || !Operand<float>(args, 1, ffi::DataType::F32, &b.cond, &cond_last) ||
+      !Operand<float>(args, 2, ffi::DataType::F32, &b.g_x0, &x_dim))
+    return Invalid("xt_hist / cond / g_x0 must be f32");
+  if (b.cond == nullptr) cond_last = 0;
+  if (ffi::Error e = Marshal(args, attrs, x_dim, cond_last, &d, &p, &s); e.failure()) return e;
+  d.want_history = 1;
+  size_t out = 0;
+  if (!Output<float>(rets, out++, ffi::DataType::F32, &b.g_xT)) return Invalid("result 0 (g_xT) must be f32");
+  for (int l = 0; l <= d.n_hidden; ++l)
+    if (!Output<float>(rets, out++, ffi::DataType::F32, &b.grad_kernel[l]) || !Output<float>(rets, out++, ffi::DataType::F32, &b.grad_bias[l]))
+      return Invalid("results: (grad_kernel_i, grad_bias_i) for i = 0..L, f32");
+  if (!Output<float>(rets, out++, ffi::DataType::F32, &b.grad_tb)) return Invalid("result grad_tb (T, H) must be f32");
+  if (AttrOr<int32_t>(attrs, "native_time", 0)) {
+    for (int k = 0; k < 2; ++k)
+      if (!Output<float>(rets, out++, ffi::DataType::F32, &b.grad_tmlp_kernel[k]) || !Output<float>(rets, out++, ffi::DataType::F32, &b.grad_tmlp_bias[k]))
+        return Invalid("native_time = 1: results grad MLP_0/Dense_{0,1} kernel, bias");
+    if (d.time_embed == FRL_TEMB_FOURIER && !Output<float>(rets, out++, ffi::DataType::F32, &b.grad_time_kernel))
+      return Invalid("native_time = 1 with a Fourier embedding: result grad time_embedding/kernel");
+  } else {
+    b.grad_bias[0] = nullptr;      // the binding differentiates the time branch itself from grad_tb (jax.vjp)
+  }
+  const size_t need = frl_bwd_workspace_bytes(&d);
+  if (need == 0) return FromRc(frl_sampler_bwd(&d, &p, &s, &b, nullptr, 0, (void*)stream));   // says why
+  auto ws = scratch.Allocate(need, 256);
+  if (!ws.has_value()) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "scratch allocation failed (the VJP stash grows with B * T * L)");
+  return FromRc(frl_sampler_bwd(&d, &p, &s, &b, *ws, need, (void*)stream));
+}
+
+}  // namespace
+
+XLA_FFI_DEFINE_HANDLER_SYMBOL(FrlSamplerFwd, FrlSamplerFwdImpl,
+                              ffi::Ffi::Bind()
+                                  .Ctx<ffi::PlatformStream<hipStream_t>>()
+                                  .Ctx<ffi::ScratchAllocator>()
+                                  .RemainingArgs()
+                                  .RemainingRets()
+                                  .Attrs());
+
+XLA_FFI_DEFINE_HANDLER_SYMBOL(FrlSamplerBwd, FrlSamplerBwdImpl,
+                              ffi::Ffi::Bind()
+                                  .Ctx<ffi::PlatformStream<hipStream_t>>()
+                                  .Ctx<ffi::ScratchAllocator>()
+                                  .RemainingArgs()
+                                  .RemainingRets()
+                                  .Attrs());

@@ -19,7 +19,7 @@
  * `stream` (no host synchronisation) and return 0 on success or a negative FRL_E* code; the
  * message is available from frl_last_error() (thread-local).  Shape validation happens before
  * any launch.  The XLA-FFI handler (csrc/xla_ffi_shim.cc, compiled only where jaxlib's headers
- * exist) is a thin translation onto frl_sampler_fwd; INTEGRATION.md shows the binding.
+ * exist) is a thin translation onto frl_sampler_fwd / frl_sampler_bwd; INTEGRATION.md shows the binding.
  */
 #ifndef FLOWRL_HIP_H_
 #define FLOWRL_HIP_H_

@@ -125,3 +125,22 @@ def test_cpu_tensor_is_refused():
     model = H.product_model(c, params, device="cpu")
     with pytest.raises(RuntimeError, match="GPU only"):
         model.sample(None, torch.from_numpy(xT), torch.from_numpy(cond), noise=torch.from_numpy(noise))
+
+
+def test_ffi_shim_compile_smoke():
+    """COMPILE SMOKE ONLY: `g++ -fsyntax-only` of flow-rl_amd/csrc/xla_ffi_shim.cc against tests/ffi_stub (a minimal
+    in-tree declaration of the xla::ffi names the shim uses — NOT jaxlib's header, which this image lacks).  Catches
+    typos, missing includes (hipStream_t) and handler-signature / binding mismatches; says nothing about jaxlib."""
+    import shutil
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    gxx = shutil.which("g++")
+    if gxx is None or not Path("/opt/rocm/include/hip/hip_runtime_api.h").exists():
+        pytest.skip("g++ or the HIP runtime headers are not available")
+    r = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-D__HIP_PLATFORM_AMD__", f"-I{root / 'tests' / 'ffi_stub'}",
+                        f"-I{root / 'include'}", "-I/opt/rocm/include", str(root / "flow-rl_amd" / "csrc" / "xla_ffi_shim.cc")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    src = (root / "flow-rl_amd" / "csrc" / "xla_ffi_shim.cc").read_text()
+    for sym in ("FrlSamplerFwd", "FrlSamplerBwd", "frl_sampler_fwd(", "frl_sampler_bwd(", "rng_impl", "cond_embed", "layer_norm", "dtype"):
+        assert sym in src, sym
