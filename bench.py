@@ -104,26 +104,39 @@ def sample(model, w, xT, cond, noise):
 def vjp_step(model, w, xT, cond, noise, g):
     """One DQL actor-update worth of sampler work: forward keeping history[0], then the chain VJP."""
     cd = w.get("dtype", "f32")
-    _, x0, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, cache_prepare=False)
-    grads, _ = model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
+    stash = cd == "f32" and not w.get("recompute")     # f32: the training forward keeps the stash, the backward only sweeps
+    _, x0, hist = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, keep_for_vjp=stash)
+    grads, _ = model.sample_vjp(hist[0], g, cond, "ddpm", want_gxT=False, compute_dtype=cd, ctx=hist[2] if stash else None)
     return x0, grads
 
 
-def vjp_only_ms(model, w, xT, cond, noise, g, iters):
-    """Average duration of the backward call alone (frl_sampler_bwd: prepare + sweep + dW kernels, plus the host's
-    O(T D^2) time-branch autograd), events on the launch stream."""
+def vjp_parts_ms(model, w, xT, cond, noise, g, iters):
+    """Average durations of the two calls of a VJP step, events on the launch stream: the forward that keeps what the
+    backward needs (f32: frl_sampler_fwd_train; bf16 / --recompute: frl_sampler_fwd with history) and the backward call
+    (frl_sampler_bwd: [recompute +] sweep + dW + reduce + time-branch kernels)."""
     cd = w.get("dtype", "f32")
-    _, _, (xh, _) = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, cache_prepare=False)
+    stash = cd == "f32" and not w.get("recompute")
+
+    def fwd():
+        return model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, keep_for_vjp=stash)[2]
+
+    def bwd(hist):
+        model.sample_vjp(hist[0], g, cond, "ddpm", want_gxT=False, compute_dtype=cd, ctx=hist[2] if stash else None)
+
+    hist = fwd()
     for _ in range(2):
-        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(xT.device)
-    e0.record()
-    for _ in range(iters):
-        model.sample_vjp(xh, g, cond, "ddpm", want_gxT=False, compute_dtype=cd)
-    e1.record()
-    torch.cuda.synchronize(xT.device)
-    return e0.elapsed_time(e1) / iters
+        bwd(hist)
+    out = []
+    for fn in (fwd, lambda: bwd(hist)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(xT.device)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(xT.device)
+        out.append(e0.elapsed_time(e1) / iters)
+    return out[0], out[1]
 
 
 def kernel_only_ms(model, w, xT, cond, noise, iters):
@@ -324,6 +337,7 @@ def main():
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
+    ap.add_argument("--recompute", action="store_true", help="cfg5 f32: plain forward with history + a backward that recomputes every step (round-1 path) instead of the training forward's stash")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU / gloo stand-in of the rank body (no GPU, not a measurement)")
     args = ap.parse_args()
 
@@ -362,6 +376,7 @@ def main():
     w["rng"] = args.rng
     w["rng_shard"] = None   # set below for N > 1: every rank draws its block of the job-wide normal(key_j, (N B, A))
     w["cache_prepare"] = bool(args.cache_prepare)
+    w["recompute"] = bool(args.recompute)
     if args.act:
         w["act"] = args.act
     if args.layers > 0:
@@ -424,12 +439,16 @@ def main():
         kname = "frl_sampler_lat_kernel" if (lat and args.dtype == "f32") else "frl_sampler_rs_kernel"
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
-            b_ms = vjp_only_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
-            kname = ("frl_sampler_bf16_kernel (no history) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel + frl_bwd_dw_bf16_kernel)"
+            f_ms, b_ms = vjp_parts_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
+            stash = args.dtype == "f32" and not args.recompute
+            kname = ("frl_sampler_fwd (bf16, history) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel [recompute + backward] + frl_bwd_dw_bf16_kernel + frl_bwd_reduce_kernel)"
                      if args.dtype == "bf16" else
-                     "frl_sampler_rs_kernel (no history) + frl_sampler_bwd call (frl_bwd_sweep_kernel + frl_bwd_dw_kernel)")
-            flops_exec = 4.0 * flops_exec
-            flops_alg, k_ms = 3.0 * flops_alg, k_ms + b_ms
+                     "frl_sampler_fwd_train (frl_bwd_sweep_kernel<PHASE 1>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 2> + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)"
+                     if stash else
+                     "frl_sampler_fwd (history) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 0> [recompute + backward] + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)")
+            flops_exec = (3.0 if stash else 4.0) * flops_exec
+            flops_alg, k_ms = 3.0 * flops_alg, f_ms + b_ms
+            vjp_parts = {"forward_ms": f_ms, "backward_ms": b_ms}
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         if args.dtype == "bf16" and not vjp:
@@ -450,6 +469,8 @@ def main():
                          "flops_executed_mfma": flops_exec,
                          "achieved_executed": flops_exec / (k_ms * 1e-3) / 1e12},
         }
+        if vjp:
+            out["roofline"].update(vjp_parts)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
     if world > 1:

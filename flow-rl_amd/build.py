@@ -24,9 +24,10 @@ OUT = HERE / "flowrl_hip" / "libflowrl_hip.so"
 ARCH = "gfx950"
 # (source, object stem, extra defines); the register-streamed sampler is one translation unit per activation
 SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []),
-           ("cond_embed.hip", "cond_embed", []), ("critic_select.hip", "critic_select", []), ("time_bwd.hip", "time_bwd", []), ("rng.hip", "rng", []), ("sampler_bwd.hip", "sampler_bwd", []),
+           ("cond_embed.hip", "cond_embed", []), ("critic_select.hip", "critic_select", []), ("time_bwd.hip", "time_bwd", []), ("rng.hip", "rng", []),
            ("sampler_bf16.hip", "sampler_bf16", ["-fno-slp-vectorize"]),
            ("sampler_bwd_bf16.hip", "sampler_bwd_bf16", ["-fno-slp-vectorize"])] + \
+          [("sampler_bwd.hip", f"sampler_bwd_p{p}", [f"-DFRL_BWD_PHASE={p}"]) for p in range(3)] + \
           [("sampler_rs.hip", f"sampler_rs_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(6)] + \
           [("sampler_lat.hip", f"sampler_lat_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(6)]
 HEADERS = [CSRC / "frl_internal.h", CSRC / "frl_device.h", CSRC / "frl_bf16.h", CSRC / "frl_rng.h", ROOT / "include" / "flowrl_hip.h"]

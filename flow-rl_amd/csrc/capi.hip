@@ -411,6 +411,84 @@ size_t frl_bwd_workspace_bytes(const FrlDesc* desc) {
   return bp.total_floats * sizeof(float);
 }
 
+// Kernel arguments shared by the training forward and the backward: forward tables + stash / image pointers of the workspace.
+static void fill_bwd_args(const FrlDesc* desc, const FrlParams* params, const Plan& pl, const BwdPlan& bp, const BwdPlan16& bp16,
+                          bool bf16, float* ws, const float* cond, BArgs& b) {
+  memset(&b, 0, sizeof(b));
+  KArgs& a = b.k;
+  a.cond = cond;
+  for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; b.wt[l - 1] = bf16 ? nullptr : ws + bp.off_wt[l - 1]; }
+  a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
+  a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
+  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
+  a.NE = pl.NE; a.AO = pl.AO;
+  a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
+  a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
+  a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
+  if (bf16) {
+    a.ws_bf16 = ws + pl.off_bf16;
+    a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
+    b.hd = ws + bp16.off_hd; b.ad = ws + bp16.off_ad; b.gd = ws + bp16.off_gd; b.ge = ws + bp16.off_ge;
+  } else {
+    b.ws_wlt = ws + bp.off_wlt; b.ws_w0xq = ws + bp.off_w0xq;
+    b.hd = ws + bp.off_hd; b.ad = ws + bp.off_ad; b.gd = ws + bp.off_gd; b.ge = ws + bp.off_ge;
+  }
+  b.Dp = pl.Dp;
+  b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
+  b.part = ws + (bf16 ? bp16.off_part : bp.off_part);
+  b.n_part = bf16 ? bp16.n_part : bp.n_part;
+}
+
+int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* bufs,
+                          void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = validate_bwd(desc);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
+  if (desc->dtype != FRL_DTYPE_F32) { set_error("training forward: f32 only (bf16: frl_sampler_fwd + frl_sampler_bwd, which recomputes)"); return FRL_EUNSUPPORTED; }
+  if (!desc->want_history) { set_error("training forward: desc.want_history must be 1 (the backward reads xt_hist / eps_hist)"); return FRL_EINVAL; }
+  BwdPlan bp;
+  BwdPlan16 bp16;
+  memset(&bp16, 0, sizeof(bp16));
+  bwd_plan_from_desc(*desc, bp);
+  const Plan& pl = bp.f;
+  if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (workspace_bytes < bp.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B (frl_bwd_workspace_bytes)", workspace_bytes, bp.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  float* ws = (float*)workspace;
+  const bool rng = desc->rng_impl != FRL_RNG_NONE;
+  const bool needs_noise = (desc->kind != FRL_KIND_CNF) && desc->solver == FRL_SOLVER_DDPM;
+  if (pl.B == 0) {
+    if (rng && bufs->rng_key != nullptr)
+      return launch_rng_chain(bufs->rng_key, desc->rng_impl, pl.mode, pl.T, (uint32_t*)(ws + pl.off_keys), bufs->rng_out, stream);
+    return FRL_OK;
+  }
+  if (bufs->xT == nullptr || bufs->x0 == nullptr || bufs->xt_hist == nullptr || bufs->eps_hist == nullptr) { set_error("bufs.xT / x0 / xt_hist / eps_hist is NULL"); return FRL_EINVAL; }
+  if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
+  if (rng && bufs->rng_key == nullptr) { set_error("desc.rng_impl = %d but bufs.rng_key is NULL", desc->rng_impl); return FRL_EINVAL; }
+  if (rng && bufs->rng_total_chains != 0 && (bufs->rng_chain_offset < 0 || bufs->rng_chain_offset + pl.B > bufs->rng_total_chains)) {
+    set_error("bufs.rng_chain_offset / rng_total_chains do not cover this call's chains"); return FRL_EINVAL; }
+  if (needs_noise && !rng && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step (or set desc.rng_impl and bufs.rng_key)"); return FRL_EINVAL; }
+  rc = frl_sampler_prepare(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream);
+  if (rc != FRL_OK) return rc;
+  BArgs b;
+  fill_bwd_args(desc, params, pl, bp, bp16, false, ws, bufs->cond, b);
+  KArgs& a = b.k;
+  a.xT = bufs->xT; a.x0 = bufs->x0; a.xt_hist = bufs->xt_hist; a.eps_hist = bufs->eps_hist;
+  const bool draw = rng && needs_noise && bufs->noise == nullptr;
+  a.noise = (needs_noise && !draw) ? bufs->noise : nullptr;
+  if (rng) {
+    uint32_t* keys = (uint32_t*)(ws + pl.off_keys);
+    rc = launch_rng_chain(bufs->rng_key, desc->rng_impl, pl.mode, pl.T, keys, bufs->rng_out, stream);
+    if (rc != FRL_OK) return rc;
+    if (draw) {
+      a.rng_keys = keys; a.rng_impl = desc->rng_impl;
+      a.rng_off = bufs->rng_total_chains > 0 ? bufs->rng_chain_offset : 0;
+      a.rng_total = bufs->rng_total_chains > 0 ? bufs->rng_total_chains : pl.B;
+    }
+  }
+  return launch_sampler_bwd(*desc, b, 1, stream);
+}
+
 int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlBwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream) {
   int rc = validate_bwd(desc);
@@ -418,6 +496,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
   BwdPlan bp;
   BwdPlan16 bp16;
+  memset(&bp16, 0, sizeof(bp16));
   const bool bf16 = desc->dtype == FRL_DTYPE_BF16;
   if (bf16) { bwd16_plan_from_desc(*desc, bp16); bp.f = bp16.f; bp.total_floats = bp16.total_floats; }
   else bwd_plan_from_desc(*desc, bp);
@@ -428,49 +507,30 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   if (pl.B == 0) return FRL_OK;
   if (bufs->xt_hist == nullptr || bufs->g_x0 == nullptr || bufs->grad_tb == nullptr) { set_error("bufs.xt_hist / g_x0 / grad_tb is NULL"); return FRL_EINVAL; }
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
+  const bool stash = bufs->have_stash != 0;
+  if (stash && bf16) { set_error("have_stash: the bf16 VJP has no training forward (it recomputes)"); return FRL_EUNSUPPORTED; }
+  if (stash && bufs->eps_hist == nullptr) { set_error("have_stash = 1 needs bufs.eps_hist (history[1] of frl_sampler_fwd_train)"); return FRL_EINVAL; }
   for (int l = 0; l <= desc->n_hidden; ++l) {
     if (bufs->grad_kernel[l] == nullptr) { set_error("bufs.grad_kernel[%d] is NULL", l); return FRL_EINVAL; }
     if (l > 0 && bufs->grad_bias[l] == nullptr) { set_error("bufs.grad_bias[%d] is NULL", l); return FRL_EINVAL; }
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  // forward tables (coefficients, tb, packed edge layers), then the transposed images
-  rc = frl_sampler_prepare(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream);
-  if (rc != FRL_OK) return rc;
   float* ws = (float*)workspace;
+  // forward tables (coefficients, tb, packed edge layers) — already there after frl_sampler_fwd_train — then the transposed images
+  if (!stash) {
+    rc = frl_sampler_prepare(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream);
+    if (rc != FRL_OK) return rc;
+  }
   rc = bf16 ? launch_prepare_bwd_bf16(*params, bp16, ws, stream) : launch_prepare_bwd(*params, bp, ws, stream);
   if (rc != FRL_OK) return rc;
   // every gradient leaf is WRITTEN once by frl_bwd_reduce_kernel (fixed-order sum of per-workgroup partial tiles in the
   // workspace): no float atomics, no zero-fill, bitwise reproducible
-  const int Dp = pl.Dp;
-
   BArgs b;
-  memset(&b, 0, sizeof(b));
-  KArgs& a = b.k;
-  a.cond = bufs->cond;
-  for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; b.wt[l - 1] = bf16 ? nullptr : ws + bp.off_wt[l - 1]; }
-  a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
-  a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
-  a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
-  a.NE = pl.NE; a.AO = pl.AO;
-  a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
-  a.mode = pl.mode; a.clip = desc->clip ? 1 : 0; a.x_min = desc->x_min; a.x_max = desc->x_max;
-  a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
-  b.xt_hist = bufs->xt_hist; b.g_x0 = bufs->g_x0; b.g_xT = bufs->g_xT;
-  if (bf16) {
-    a.ws_bf16 = ws + pl.off_bf16;
-    a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
-    b.hd = ws + bp16.off_hd; b.ad = ws + bp16.off_ad; b.gd = ws + bp16.off_gd; b.ge = ws + bp16.off_ge;
-  } else {
-    b.ws_wlt = ws + bp.off_wlt; b.ws_w0xq = ws + bp.off_w0xq;
-    b.hd = ws + bp.off_hd; b.ad = ws + bp.off_ad; b.gd = ws + bp.off_gd; b.ge = ws + bp.off_ge;
-  }
+  fill_bwd_args(desc, params, pl, bp, bp16, bf16, ws, bufs->cond, b);
+  b.xt_hist = bufs->xt_hist; b.g_x0 = bufs->g_x0; b.g_xT = bufs->g_xT; b.eps_hist = bufs->eps_hist;
   for (int l = 0; l <= pl.L; ++l) { b.grad_kernel[l] = bufs->grad_kernel[l]; b.grad_bias[l] = bufs->grad_bias[l]; }
   b.grad_tb = bufs->grad_tb;
-  b.Dp = Dp;
-  b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
-  b.part = ws + (bf16 ? bp16.off_part : bp.off_part);
-  b.n_part = bf16 ? bp16.n_part : bp.n_part;
-  rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stream);
+  rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stash ? 2 : 0, stream);
   if (rc != FRL_OK) return rc;
   const bool native_time = (desc->time_embed == FRL_TEMB_NONE) ? (bufs->grad_bias[0] != nullptr) : (bufs->grad_tmlp_kernel[0] != nullptr);
   if (!native_time) return FRL_OK;

@@ -218,6 +218,7 @@ inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
 struct BArgs {
   KArgs k;                        // forward arguments (xT unused; k.noise unused)
   const float* xt_hist; const float* g_x0; float* g_xT;
+  const float* eps_hist;          // history[1] of the training forward (phase 2 only)
   const float* wt[FRL_MAX_HIDDEN - 1];  // transposed hidden kernels
   const float* ws_wlt; const float* ws_w0xq;
   float* hd; float* ad; float* gd; float* ge;
@@ -280,7 +281,11 @@ int launch_random_split(const uint32_t* key, int impl, int num, uint32_t* out, h
 int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, int kind, hipStream_t stream);   // 0 bits, 1 normal, 2 gumbel
 
 int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
-int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, hipStream_t stream);
+int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, int phase, hipStream_t stream);   // phase 0 recompute + backward, 1 training forward, 2 backward from the stash
+template <int PHASE> int launch_bwd_sweep_phase(const FrlDesc& d, const BArgs& b, hipStream_t stream);   // one translation unit each
+template <> int launch_bwd_sweep_phase<0>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
+template <> int launch_bwd_sweep_phase<1>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
+template <> int launch_bwd_sweep_phase<2>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
 

@@ -23,6 +23,13 @@
 // Weight gradients contract over CHAINS (the lane axis of the sweep), so they cannot be accumulated inside the
 // sweep without 64 K accumulators per wave: the stash (3 x 32 KB per tile-step and layer) is what links the two.
 #include "frl_device.h"
+#include "frl_rng.h"
+
+// One translation unit per sweep phase (-DFRL_BWD_PHASE=0|1|2, flow-rl_amd/build.py) so the three heavy instantiation sets
+// compile in parallel; the phase-0 unit also carries the prepare, dW and reduce kernels.
+#ifndef FRL_BWD_PHASE
+#error "compile with -DFRL_BWD_PHASE=<0|1|2>"
+#endif
 
 namespace frl {
 
@@ -66,6 +73,7 @@ __device__ __forceinline__ void act_grad2(f32x2 z, f32x2& h, f32x2& d) {
   }
 }
 
+#if FRL_BWD_PHASE == 0
 // ---- preparation: transposed / packed weight images -------------------------------------------------------
 struct PBArgs {
   const float* kernel[FRL_MAX_HIDDEN + 1];
@@ -116,8 +124,15 @@ int launch_prepare_bwd(const FrlParams& prm, const BwdPlan& bp, float* ws, hipSt
   return FRL_OK;
 }
 
+#endif  // FRL_BWD_PHASE == 0
+
 // ---- the sweep ---------------------------------------------------------------------------------------------
-template <int ACT, int NRX, int CKMAX>
+// PHASE 0: recompute + backward in one kernel (the caller kept only xt_hist: frl_sampler_bwd without a stash)
+// PHASE 1: the TRAINING FORWARD (frl_sampler_fwd_train): the sampler itself, steps j = 0 .. T-1 with the update rule,
+//          writing x0, xt_hist, eps_hist AND the stash (h_l, act'(z_l)) the backward needs — so that
+// PHASE 2: the backward sweep alone (steps T-1 .. 0) reads eps_hist and act' instead of recomputing the forward:
+//          a third of the sweep's MFMA work and its two stash writes leave the backward call.
+template <int ACT, int NRX, int CKMAX, int PHASE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_bwd_sweep_kernel(const BArgs b) {
   typedef Geo<32> G;
@@ -206,28 +221,9 @@ frl_bwd_sweep_kernel(const BArgs b) {
       const int k = KS * c + ls;
       cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
     });
-    float gx[NRX];      // dL/dx_{j+1}, same register layout as the chain state
-    sfor<NRX>([&](auto RI) {
-      constexpr int r = decltype(RI)::value;
-      const int ai = G::rowr(r) + 4 * ls;
-      gx[r] = (valid && ai < a.A) ? b.g_x0[chain * a.A + ai] : 0.0f;
-    });
-
-    for (int jj = 0; jj < a.T; ++jj) {
-      const int j = a.T - 1 - jj;
-      const long long ts = wt * a.T + j;
-      const size_t srow = (size_t)ts * a.L * 8192;          // floats; each layer = 8192 floats = 64 pair rows x 512 B
-      const __amdgpu_buffer_rsrc_t rs_hd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.hd + srow), 0, a.L * 32768, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 32768, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_gd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.gd + srow), 0, a.L * 32768, 0x00020000);
-
-      float xs[NRX];
-      sfor<NRX>([&](auto RI) {
-        constexpr int r = decltype(RI)::value;
-        const int ai = G::rowr(r) + 4 * ls;
-        xs[r] = (valid && ai < a.A) ? b.xt_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
-      });
-
+    // forward of one step from the chain state xs: Dense_0, hidden layers, Dense_L -> O (= eps / velocity); every
+    // layer's h = act(z) and act'(z) go to the stash rows rs_hd / rs_ad of this tile-step
+    auto forward_step = [&](int j, const float (&xs)[NRX], __amdgpu_buffer_rsrc_t rs_hd, __amdgpu_buffer_rsrc_t rs_ad, acc_t& O) {
       // ================= forward of step j, recomputed =====================================================
       sfor<RING - 1>([&](auto NI) { l0load(NI); });
       bias_init(P, s_tb + j * H);
@@ -281,7 +277,6 @@ frl_bwd_sweep_kernel(const BArgs b) {
       }
 
       // Dense_L -> eps
-      acc_t O;
       sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[G::rowr(r) + 4 * ls]; });
       {
         f32x4 rl[RINGL];
@@ -306,6 +301,109 @@ frl_bwd_sweep_kernel(const BArgs b) {
           }
           O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
           bop = bn1; bn1 = bn2;
+        });
+      }
+    };
+
+    if constexpr (PHASE == 1) {
+      // ===================== training forward: the sampler's own loop, stash kept =====================================
+      float xs[NRX];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        xs[r] = (valid && ai < a.A) ? a.xT[chain * a.A + ai] : 0.0f;
+      });
+      for (int j = 0; j < a.T; ++j) {
+        const long long ts = wt * a.T + j;
+        const size_t srow = (size_t)ts * a.L * 8192;
+        const __amdgpu_buffer_rsrc_t rs_hd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.hd + srow), 0, a.L * 32768, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 32768, 0x00020000);
+        float zr[NRX];
+        sfor<NRX>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int ai = G::rowr(r) + 4 * ls;
+          const bool in = valid && ai < a.A;
+          if (a.rng_impl != FRL_RNG_NONE && a.noise == nullptr)
+            zr[r] = (in && s_coef[j * COEF_STRIDE + 5] != 0.0f) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai) : 0.0f;
+          else
+            zr[r] = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        });
+        acc_t O;
+        forward_step(j, xs, rs_hd, rs_ad, O);
+        const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
+        const float c2 = s_coef[j * COEF_STRIDE + 2], c3 = s_coef[j * COEF_STRIDE + 3];
+        const float c4 = s_coef[j * COEF_STRIDE + 4], c5 = s_coef[j * COEF_STRIDE + 5];
+        sfor<NRX>([&](auto RI) {           // the update rules of frl_sampler_rs_kernel's epilogue (sampler_rs.hip), verbatim
+          constexpr int r = decltype(RI)::value;
+          const int ai = G::rowr(r) + 4 * ls;
+          const bool in = valid && ai < a.A;
+          const float eps = O[r], xt = xs[r];
+          if (in) {
+            const long long o = ((long long)j * a.B + chain) * a.A + ai;
+            a.xt_hist[o] = xt;
+            a.eps_hist[o] = eps;
+          }
+          float xn;
+          if (a.mode == MODE_DDPM_DDPM) {
+            float x0h = c0 * (xt - c1 * eps);
+            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+            xn = c2 * (c3 * x0h + c4 * xt);
+            xn += c5 * zr[r];
+          } else if (a.mode == MODE_DDPM_DDIM) {
+            xn = c0 * (xt - c1 * eps) + c2 * eps;
+            if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+          } else if (a.mode == MODE_CDDPM_DDPM) {
+            float x0h = (xt - c1 * eps) / c0;
+            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+            xn = c2 * x0h + c3 * xt;
+            xn += c5 * zr[r];
+          } else if (a.mode == MODE_CDDPM_DDIM) {
+            float x0h = (xt - c1 * eps) / c0;
+            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+            xn = c2 * x0h + c3 * eps;
+          } else {
+            xn = xt + eps / c0;
+            if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+          }
+          xs[r] = in ? xn : 0.0f;
+        });
+      }
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        if (valid && ai < a.A) a.x0[chain * a.A + ai] = xs[r];
+      });
+    } else {
+    float gx[NRX];      // dL/dx_{j+1}, same register layout as the chain state
+    sfor<NRX>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      const int ai = G::rowr(r) + 4 * ls;
+      gx[r] = (valid && ai < a.A) ? b.g_x0[chain * a.A + ai] : 0.0f;
+    });
+
+    for (int jj = 0; jj < a.T; ++jj) {
+      const int j = a.T - 1 - jj;
+      const long long ts = wt * a.T + j;
+      const size_t srow = (size_t)ts * a.L * 8192;          // floats; each layer = 8192 floats = 64 pair rows x 512 B
+      const __amdgpu_buffer_rsrc_t rs_hd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.hd + srow), 0, a.L * 32768, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 32768, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_gd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.gd + srow), 0, a.L * 32768, 0x00020000);
+
+      float xs[NRX];
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        xs[r] = (valid && ai < a.A) ? b.xt_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+      });
+
+      acc_t O;
+      if constexpr (PHASE == 0) {
+        forward_step(j, xs, rs_hd, rs_ad, O);             // the caller kept only xt_hist: recompute the step
+      } else {
+        sfor<NRX>([&](auto RI) {                           // the training forward kept eps_hist and the stash
+          constexpr int r = decltype(RI)::value;
+          const int ai = G::rowr(r) + 4 * ls;
+          O[r] = (valid && ai < a.A) ? b.eps_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         });
       }
 
@@ -438,9 +536,11 @@ frl_bwd_sweep_kernel(const BArgs b) {
         if (valid && ai < a.A) b.g_xT[chain * a.A + ai] = gx[r];
       });
     }
+    }   // PHASE != 1
   }
 }
 
+#if FRL_BWD_PHASE == 0
 // ---- weight gradients: split-K GEMM over the stash -------------------------------------------------------------
 // One workgroup (4 waves, 2 x 2) owns tile-steps ts = blockIdx, blockIdx + grid, ... and, layer after layer, the whole
 // dW_l tile in accumulators.  Per tile-step the two operands (X = inputs of the layer, G = dL/dz of the layer, both
@@ -676,10 +776,12 @@ frl_bwd_dw_kernel(const BArgs b) {
   dw_layer_f32<2>(b, a.L, smem_dw, u0, u1, n_wt);
 }
 
+#endif  // FRL_BWD_PHASE == 0
+
 // ---- launcher ---------------------------------------------------------------------------------------------------
 template <int ACT>
 static int launch_sweep(const BArgs& b, int grid, int block, size_t lds, hipStream_t stream) {
-  auto kern = frl_bwd_sweep_kernel<ACT, 4, 12>;
+  auto kern = frl_bwd_sweep_kernel<ACT, 4, 12, FRL_BWD_PHASE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, b);
@@ -688,12 +790,10 @@ static int launch_sweep(const BArgs& b, int grid, int block, size_t lds, hipStre
   return FRL_OK;
 }
 
-int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
+template <>
+int launch_bwd_sweep_phase<FRL_BWD_PHASE>(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
   const KArgs& a = b.k;
-  int dev = 0, ncu = 256;
-  (void)hipGetDevice(&dev);
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+  const int ncu = device_cus();
   const long long n_wt = (a.B + 31) / 32;
   long long per_cu = (n_wt + ncu - 1) / ncu;
   int nw = (int)(per_cu < 1 ? 1 : (per_cu > MAX_WAVES ? MAX_WAVES : per_cu));
@@ -702,13 +802,19 @@ int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
   const int grid = (int)(nwg < ncu ? nwg : ncu);
   const size_t lds = sizeof(float) * ((size_t)a.T * 256 + (size_t)(a.L - 1) * 256 + LAST_PAD + (size_t)a.T * COEF_STRIDE);
   if (lds > 160 * 1024) { set_error("bwd: steps=%d needs %zu B of LDS", a.T, lds); return FRL_EUNSUPPORTED; }
-  int rc;
   switch (d.act) {
-    case FRL_ACT_MISH: rc = launch_sweep<FRL_ACT_MISH>(b, grid, 64 * nw, lds, stream); break;
-    case FRL_ACT_SILU: rc = launch_sweep<FRL_ACT_SILU>(b, grid, 64 * nw, lds, stream); break;
-    case FRL_ACT_RELU: rc = launch_sweep<FRL_ACT_RELU>(b, grid, 64 * nw, lds, stream); break;
+    case FRL_ACT_MISH: return launch_sweep<FRL_ACT_MISH>(b, grid, 64 * nw, lds, stream);
+    case FRL_ACT_SILU: return launch_sweep<FRL_ACT_SILU>(b, grid, 64 * nw, lds, stream);
+    case FRL_ACT_RELU: return launch_sweep<FRL_ACT_RELU>(b, grid, 64 * nw, lds, stream);
     default: set_error("bwd: activation %d has no VJP kernel (mish / silu / relu)", d.act); return FRL_EUNSUPPORTED;
   }
+}
+
+#if FRL_BWD_PHASE == 0
+// phase 1: the training forward alone; phase 0 / 2: the sweep (with / without recompute), the dW kernel and the reduce
+int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, int phase, hipStream_t stream) {
+  if (phase == 1) return launch_bwd_sweep_phase<1>(d, b, stream);
+  int rc = (phase == 2) ? launch_bwd_sweep_phase<2>(d, b, stream) : launch_bwd_sweep_phase<0>(d, b, stream);
   if (rc != FRL_OK) return rc;
   const long long g2 = b.n_part;                        // one partial slot per workgroup (BwdPlan.n_part)
   const size_t lds2 = sizeof(float) * 4 * 256 * 33;     // two (X, G) tile pairs
@@ -719,5 +825,6 @@ int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
   if (e != hipSuccess) { set_error("bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return launch_bwd_reduce(b, stream);
 }
+#endif
 
 }  // namespace frl

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FRL_ABI_VERSION = 3
+FRL_ABI_VERSION = 4
 FRL_MAX_HIDDEN = 8
 
 FRL_KIND_DDPM, FRL_KIND_CDDPM, FRL_KIND_CNF = 0, 1, 2
@@ -58,7 +58,8 @@ class FrlFwdBufs(C.Structure):
 class FrlBwdBufs(C.Structure):
     _fields_ = [("xt_hist", _fp), ("cond", _fp), ("g_x0", _fp), ("g_xT", _fp),
                 ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_tb", _fp),
-                ("grad_tmlp_kernel", _fp * 2), ("grad_tmlp_bias", _fp * 2), ("grad_time_kernel", _fp)]
+                ("grad_tmlp_kernel", _fp * 2), ("grad_tmlp_bias", _fp * 2), ("grad_time_kernel", _fp),
+                ("eps_hist", _fp), ("have_stash", C.c_int32)]
 
 
 class FrlCriticDesc(C.Structure):
@@ -108,6 +109,8 @@ EXPORTS = {
     "frl_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
     "frl_sampler_bwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule), C.POINTER(FrlBwdBufs),
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_sampler_fwd_train": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule), C.POINTER(FrlFwdBufs),
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_critic_workspace_bytes": (C.c_size_t, [C.POINTER(FrlCriticDesc)]),
     "frl_critic_select": (C.c_int, [C.POINTER(FrlCriticDesc), C.POINTER(FrlCriticParams), C.POINTER(FrlSelectBufs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

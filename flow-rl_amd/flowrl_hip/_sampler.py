@@ -312,12 +312,77 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
     return x0, hist
 
 
+# ---- training forward (keeps what the chain VJP needs) --------------------------------------------------------
+class VjpContext:
+    """What a training forward (frl_sampler_fwd_train) leaves for the backward: the descriptor / parameter pointers of
+    the call, its own workspace holding the stash (act(z), act'(z) of every layer and step), and the history."""
+    __slots__ = ("desc", "fparams", "fs", "keep", "ws", "xt_hist", "eps_hist", "B", "cond2d", "lead")
+
+
+def run_sampler_train(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
+                      condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
+                      clip_sampler: bool, x_min, x_max, particles: Optional[int] = None, rng_key: Optional[torch.Tensor] = None,
+                      rng_impl: Optional[str] = None, rng_shard: Optional[Tuple[int, int]] = None):
+    """sample(training=True, params=p) for a caller that will differentiate through the chain (dql.py:105-112): one
+    launch of the training-forward kernel, which is the sampler plus the stash the backward sweep reads instead of
+    recomputing.  Returns (x0, (xt_hist, eps_hist), ctx[, rng_out]); pass ``ctx`` to :func:`run_sampler_vjp`."""
+    lib = _lib.load()
+    if not xT.is_cuda:
+        raise RuntimeError("flowrl_hip samplers run on the GPU only; there is no CPU fallback")
+    device = xT.device
+    A = xT.shape[-1]
+    lead = tuple(xT.shape[:-1])
+    desc, fparams, fs, keep, B, cond2d = _marshal(
+        network, params, kind=kind, solver=solver, steps=steps, xT=xT, condition=condition, sched=sched,
+        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles,
+        rng_impl=0 if rng_key is None else _random.impl_id(rng_impl))
+    need = lib.frl_bwd_workspace_bytes(C.byref(desc))
+    if need == 0:
+        _lib.check(lib.frl_sampler_fwd_train(C.byref(desc), C.byref(fparams), C.byref(fs), None, None, 0, None))
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "this configuration has no VJP kernel")
+    x_in = _f32c(xT.reshape(B, A), device, "xT")
+    x0 = torch.empty((B, A), dtype=torch.float32, device=device)
+    xt_hist = torch.empty((steps, B, A), dtype=torch.float32, device=device)
+    eps_hist = torch.empty((steps, B, A), dtype=torch.float32, device=device)
+    bufs = _lib.FrlFwdBufs()
+    bufs.xT, bufs.x0, bufs.xt_hist, bufs.eps_hist = x_in.data_ptr(), x0.data_ptr(), xt_hist.data_ptr(), eps_hist.data_ptr()
+    if cond2d is not None:
+        bufs.cond = cond2d.data_ptr()
+    if noise is not None:
+        if noise.numel() != steps * B * A:
+            raise ValueError(f"noise has {noise.numel()} elements, expected (T, ..., A) = {steps * B * A}")
+        noise = _f32c(noise.reshape(steps, B, A), device, "noise")
+        bufs.noise = noise.data_ptr()
+    rng_out = None
+    if rng_key is not None:
+        rng_key = _random.as_key(rng_key, device)
+        rng_out = torch.empty((2,), dtype=torch.uint32, device=device)
+        bufs.rng_key, bufs.rng_out = rng_key.data_ptr(), rng_out.data_ptr()
+        if rng_shard is not None:
+            bufs.rng_chain_offset, bufs.rng_total_chains = int(rng_shard[0]), int(rng_shard[1])
+    # the context owns its workspace: the stash must survive whatever runs between forward and backward (the critic)
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        rc = lib.frl_sampler_fwd_train(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs), ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc)
+    ctx = VjpContext()
+    ctx.desc, ctx.fparams, ctx.fs, ctx.keep, ctx.ws = desc, fparams, fs, keep, ws
+    ctx.xt_hist, ctx.eps_hist, ctx.B, ctx.cond2d, ctx.lead = xt_hist, eps_hist, B, cond2d, lead
+    hist = (xt_hist.reshape(steps, *lead, A), eps_hist.reshape(steps, *lead, A))
+    if rng_key is not None:
+        return x0.reshape(*lead, A), hist, ctx, rng_out
+    return x0.reshape(*lead, A), hist, ctx
+
+
 # ---- chain VJP -----------------------------------------------------------------------------------------------
 def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int, xt_hist: torch.Tensor,
                     condition: Optional[torch.Tensor], g_x0: torch.Tensor, sched: Dict[str, torch.Tensor],
                     tvals: Optional[torch.Tensor] = None, clip_sampler: bool = False, x_min=None, x_max=None, particles: Optional[int] = None,
-                    want_gxT: bool = True, compute_dtype: str = "f32"):
-    """dL/dparams (Flax-layout tree) and dL/dxT of one sampler call, given its history[0] and dL/dx0.  Everything is
+                    want_gxT: bool = True, compute_dtype: str = "f32", ctx: Optional["VjpContext"] = None):
+    """``ctx`` (from :func:`run_sampler_train`): the backward reads that call's stash and eps_hist instead of recomputing
+    every step from xt_hist; descriptor, parameter pointers and workspace are the forward call's.
+    dL/dparams (Flax-layout tree) and dL/dxT of one sampler call, given its history[0] and dL/dx0.  Everything is
     libflowrl_hip's frl_sampler_bwd: recompute + backward sweep + weight-gradient GEMMs (O(B)), and the batch-invariant
     time branch (MLP_0, time_embedding, Dense_0's bias and time rows) from the kernel's own dL/dtb."""
     lib = _lib.load()
@@ -326,10 +391,16 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
     device = g_x0.device
     A = g_x0.shape[-1]
     lead = tuple(g_x0.shape[:-1])
-    desc, fparams, fs, keep, B, cond2d = _marshal(
-        network, params, kind=kind, solver=solver, steps=steps, xT=g_x0, condition=condition, sched=sched,
-        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles,
-        compute_dtype=compute_dtype)
+    if ctx is not None:
+        desc, fparams, fs, keep, B, cond2d = ctx.desc, ctx.fparams, ctx.fs, ctx.keep, ctx.B, ctx.cond2d
+        xt_hist = ctx.xt_hist
+    else:
+        desc, fparams, fs, keep, B, cond2d = _marshal(
+            network, params, kind=kind, solver=solver, steps=steps, xT=g_x0, condition=condition, sched=sched,
+            clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles,
+            compute_dtype=compute_dtype)
+    if g_x0.numel() != B * A:
+        raise ValueError(f"g_x0 has {g_x0.numel()} elements, expected {B * A}")
     if xt_hist.numel() != steps * B * A:
         raise ValueError(f"xt_hist has {xt_hist.numel()} elements, expected (T, ..., A) = {steps * B * A}")
     xt_hist = _f32c(xt_hist.reshape(steps, B, A), device, "xt_hist")
@@ -372,7 +443,11 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
         _lib.check(lib.frl_sampler_bwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs), None, 0, None))
         raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "this configuration has no VJP kernel")
     stream = torch.cuda.current_stream(device).cuda_stream
-    ws = _workspace(need, device, stream)
+    if ctx is not None:
+        ws = ctx.ws
+        bufs.eps_hist, bufs.have_stash = ctx.eps_hist.data_ptr(), 1
+    else:
+        ws = _workspace(need, device, stream)
     with torch.cuda.device(device):
         rc = lib.frl_sampler_bwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs),
                                  ws.data_ptr(), ws.numel(), stream)

@@ -9,7 +9,7 @@ import torch
 
 from .. import _lib
 from .. import random as _random
-from .._sampler import run_sampler, run_sampler_vjp
+from .._sampler import run_sampler, run_sampler_train, run_sampler_vjp
 from ..module import FlowBackbone, init_params
 
 
@@ -39,12 +39,24 @@ class ContinuousNormalizingFlow:
 
     def sample(self, rng, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                params: Optional[Dict] = None, *, history: bool = False, particles: Optional[int] = None,
-               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False):
+               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False):
         """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps.  A (2,) uint32
         threefry key as ``rng`` is advanced as the reference's scan does (cnf.py:126) and returned; anything else is
-        returned unchanged."""
+        returned unchanged.
+        ``keep_for_vjp=True`` (training callers that differentiate through the chain, dql.py:105-112): runs the training
+        forward, which also keeps act(z) / act'(z) of every layer and step; history is then (xt_hist, eps_hist, ctx) and
+        ``sample_vjp(..., ctx=ctx)`` runs the backward sweep only instead of recomputing every step."""
         key = rng if _random.is_key(rng) else None
         p = params if (training and params is not None) else self.params
+        if keep_for_vjp:
+            if compute_dtype != "f32":
+                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "keep_for_vjp: the training forward is f32 (bf16: sample(history=True) + sample_vjp, which recomputes)")
+            tout = run_sampler_train(
+            self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xT=x0,
+            condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
+            x_max=self.x_max, particles=particles, 
+            rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
+            return (tout[3] if key is not None else rng), tout[0], (tout[1][0], tout[1][1], tout[2])
         out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xT=x0,
             condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
@@ -54,7 +66,7 @@ class ContinuousNormalizingFlow:
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x1: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gx0: bool = True,
-                   compute_dtype: str = "f32"):
+                   compute_dtype: str = "f32", ctx=None):
         """VJP of :meth:`sample` w.r.t. the parameter tree and x0 (what ``jax.grad`` through the unrolled Euler scan
         cnf.py:122-141 computes), from history[0] of the forward call and dL/dx1."""
         p = params if params is not None else self.params
@@ -63,4 +75,4 @@ class ContinuousNormalizingFlow:
         return run_sampler_vjp(
             self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xt_hist=xt_hist,
             condition=condition, g_x0=g_x1, sched={}, tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
-            x_max=self.x_max, particles=particles, want_gxT=want_gx0, compute_dtype=compute_dtype)
+            x_max=self.x_max, particles=particles, want_gxT=want_gx0, compute_dtype=compute_dtype, ctx=ctx)

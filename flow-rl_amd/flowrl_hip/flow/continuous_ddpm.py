@@ -10,7 +10,7 @@ import torch
 
 from .. import _lib, schedules
 from .. import random as _random
-from .._sampler import run_sampler, run_sampler_vjp
+from .._sampler import run_sampler, run_sampler_train, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
 from .ddpm import draw_noise
 
@@ -75,7 +75,7 @@ class ContinuousDDPM:
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
                particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False):
+               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False):
         """ContinuousDDPM.sample (continuous_ddpm.py:117-222).
         ``rng``: a (2,) uint32 threefry key (flowrl_hip.random.PRNGKey / jax.random.key_data) makes the call a
         true rng-in / rng-out drop-in: the scan's split sequence runs on the GPU, the per-step noise is drawn in-kernel
@@ -94,6 +94,15 @@ class ContinuousDDPM:
         if solver == "ddpm" and noise is None and key is None:
             noise = draw_noise(rng, (steps, *xT.shape), xT.device)
         sched = self._device_tables(steps, t_schedule_n, solver == "dpm2", dev)
+        if keep_for_vjp:
+            if compute_dtype != "f32":
+                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "keep_for_vjp: the training forward is f32 (bf16: sample(history=True) + sample_vjp, which recomputes)")
+            tout = run_sampler_train(
+            self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
+            steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
+            clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
+            particles=particles, rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
+            return (tout[3] if key is not None else rng), tout[0], (tout[1][0], tout[1][1], tout[2])
         out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
@@ -104,7 +113,7 @@ class ContinuousDDPM:
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                    params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gxT: bool = True,
-                   compute_dtype: str = "f32"):
+                   compute_dtype: str = "f32", ctx=None):
         """VJP of :meth:`sample` (solvers ddpm / ddim) w.r.t. the parameter tree and xT — what DACER's actor loss
         differentiates (agent/online/dacer.py:141-162: jax.grad through continuous_ddpm.py:159-220), from history[0] of the
         forward call and dL/dx0."""
@@ -123,4 +132,4 @@ class ContinuousDDPM:
             solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM, steps=steps, xt_hist=xt_hist,
             condition=condition, g_x0=g_x0, sched={"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)},
             tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, particles=particles,
-            want_gxT=want_gxT, compute_dtype=compute_dtype)
+            want_gxT=want_gxT, compute_dtype=compute_dtype, ctx=ctx)

@@ -14,7 +14,7 @@ import torch
 
 from .. import _lib, schedules
 from .. import random as _random
-from .._sampler import run_sampler, run_sampler_vjp
+from .._sampler import run_sampler, run_sampler_train, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
 
 SUPPORTED_SOLVERS = ["ddim", "ddpm"]   # ddpm.py:16-18
@@ -67,7 +67,7 @@ class DDPM:
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: str = "ddpm", params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None,
                history: bool = False, particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
         """DDPM.sample (ddpm.py:173-221).  Extra keyword-only arguments:
         ``noise`` (T, *xT.shape): the per-iteration N(0, I) draws (iteration j <-> t = T - j);
         ``history``: also return (xt_hist, eps_hist) (ddpm.py:217); ``particles``: chains per condition
@@ -83,6 +83,17 @@ class DDPM:
         key = rng if _random.is_key(rng) else None
         if solver == "ddpm" and noise is None and key is None:
             noise = draw_noise(rng, (self.steps, *xT.shape), xT.device)
+        if keep_for_vjp:
+            if compute_dtype != "f32":
+                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "keep_for_vjp: the training forward is f32 (bf16: sample(history=True) + sample_vjp, which recomputes)")
+            tout = run_sampler_train(
+            self.network, p, kind=_lib.FRL_KIND_DDPM,
+            solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
+            steps=self.steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
+            sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
+            clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
+            particles=particles, rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
+            return (tout[3] if key is not None else rng), tout[0], (tout[1][0], tout[1][1], tout[2])
         out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_DDPM,
             solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
@@ -94,7 +105,7 @@ class DDPM:
 
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: str = "ddpm", params: Optional[Dict] = None, *, particles: Optional[int] = None,
-                   want_gxT: bool = True, compute_dtype: str = "f32") -> Tuple[Dict, Optional[torch.Tensor]]:
+                   want_gxT: bool = True, compute_dtype: str = "f32", ctx=None) -> Tuple[Dict, Optional[torch.Tensor]]:
         """VJP of :meth:`sample` w.r.t. the parameter tree and xT: what ``jax.grad`` through
         ``actor.sample(..., training=True, params=p)`` computes in the DQL actor update (dql.py:93-123 through
         ddpm.py:186-219).  ``xt_hist`` = history[0] of the forward call (``sample(..., history=True)``),
@@ -111,4 +122,4 @@ class DDPM:
             xt_hist=xt_hist, condition=condition, g_x0=g_x0,
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
-            particles=particles, want_gxT=want_gxT, compute_dtype=compute_dtype)
+            particles=particles, want_gxT=want_gxT, compute_dtype=compute_dtype, ctx=ctx)

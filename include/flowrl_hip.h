@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FRL_ABI_VERSION 3
+#define FRL_ABI_VERSION 4
 #define FRL_MAX_HIDDEN 8 /* hidden Dense layers of the predictor MLP (mlp.py:25) */
 
 /* error codes */
@@ -225,9 +225,22 @@ typedef struct FrlBwdBufs {
   float* grad_tmlp_kernel[2];
   float* grad_tmlp_bias[2];
   float* grad_time_kernel;
+  /* Set both when the forward call was frl_sampler_fwd_train on THIS workspace: the backward then reads the forward's
+   * stash (act(z), act'(z) of every layer) and eps_hist instead of recomputing every step from xt_hist. */
+  const float* eps_hist; /* (T, B, A) history[1] of that forward call, or NULL */
+  int32_t have_stash;    /* 1: the workspace holds the stash of frl_sampler_fwd_train for the same desc / params / inputs */
 } FrlBwdBufs;
 
 size_t frl_bwd_workspace_bytes(const FrlDesc* desc);
+
+/* The TRAINING forward of the sampler (sample(training=True, params=p), ddpm.py:191-194, as jit_update_actor calls it,
+ * dql.py:105-112): frl_sampler_fwd with desc.want_history = 1 that ALSO keeps, in the backward workspace
+ * (frl_bwd_workspace_bytes), what jax.grad keeps of the unrolled scan — act(z) and act'(z) of every layer and step.
+ * A following frl_sampler_bwd on the same workspace with bufs.have_stash = 1 and bufs.eps_hist then runs the backward
+ * sweep only.  Results (x0, xt_hist, eps_hist) agree with frl_sampler_fwd's to float32 rounding.  f32, the VJP's shape
+ * family (see above); FRL_EUNSUPPORTED otherwise — use frl_sampler_fwd + frl_sampler_bwd (which recomputes) there. */
+int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* bufs,
+                          void* bwd_workspace, size_t workspace_bytes, void* hip_stream);
 
 int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlBwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream);

@@ -43,33 +43,45 @@ def oracle_vjp(case, params, xT, cond, noise, g, xt_hist=None):
     return ov.cnf_sample_vjp(case.spec, params, xT, cd, g, **kw)
 
 
-def product_vjp(case, model, xT, cond, noise, g, compute_dtype="f32"):
-    """Forward with history + VJP through the product; returns (grads tree, dL/dxT, xt_hist) as torch tensors."""
+def product_vjp(case, model, xT, cond, noise, g, compute_dtype="f32", stash=False, out=None):
+    """Forward with history + VJP through the product; returns (grads tree, dL/dxT, xt_hist) as torch tensors.
+    ``stash``: the forward is the TRAINING forward (frl_sampler_fwd_train, keep_for_vjp=True) and the backward reads its
+    stash (frl_sampler_bwd with have_stash) instead of recomputing every step from xt_hist."""
     import torch
     x = torch.from_numpy(xT).cuda()
     c = None if cond is None else torch.from_numpy(cond).cuda()
     gt = torch.from_numpy(g).cuda()
     parts = case.particles if case.particles > 1 else None
-    kw = dict(history=True, particles=parts, params=model.params, compute_dtype=compute_dtype)
+    kw = dict(history=True, particles=parts, params=model.params, compute_dtype=compute_dtype, keep_for_vjp=stash)
     if case.kind == "cnf":
-        _, x0, (xh, _) = model.sample(None, x, c, True, **kw)
-        grads, gxT = model.sample_vjp(xh, gt, c, particles=parts, compute_dtype=compute_dtype)
+        _, x0, hist = model.sample(None, x, c, True, **kw)
+        grads, gxT = model.sample_vjp(hist[0], gt, c, particles=parts, compute_dtype=compute_dtype, ctx=hist[2] if stash else None)
     else:
         nz = torch.from_numpy(noise).cuda() if case.solver == "ddpm" else None
-        _, x0, (xh, _) = model.sample(None, x, c, True, case.solver, noise=nz, **kw)
-        grads, gxT = model.sample_vjp(xh, gt, c, case.solver, particles=parts, compute_dtype=compute_dtype)
-    return grads, gxT, xh
+        _, x0, hist = model.sample(None, x, c, True, case.solver, noise=nz, **kw)
+        grads, gxT = model.sample_vjp(hist[0], gt, c, case.solver, particles=parts, compute_dtype=compute_dtype, ctx=hist[2] if stash else None)
+    if out is not None:
+        out.update(x0=x0, xt_hist=hist[0], eps_hist=hist[1])
+    return grads, gxT, hist[0]
 
 
-def _run(case):
+def _run(case, stash=False):
     import torch
     params, xT, cond, noise = H.make_inputs(case)
     rng = np.random.default_rng(77 + case.seed)
     g = rng.standard_normal((case.B, case.A)).astype(np.float32)
     x0_ref, gref, gx_ref = oracle_vjp(case, params, xT, cond, noise, g)
     model = H.product_model(case, params)
-    grads, gxT, _ = product_vjp(case, model, xT, cond, noise, g)
+    fwd = {}
+    grads, gxT, _ = product_vjp(case, model, xT, cond, noise, g, stash=stash, out=fwd)
     torch.cuda.synchronize()
+    if stash:
+        # the training forward IS the sampler: its x0 / history against the float64 oracle at the forward's own bar
+        r0, rx, re = H.oracle_run(case, params, xT, cond, noise, dtype=np.float64)
+        o32 = H.oracle_run(case, params, xT, cond, noise, dtype=np.float32)
+        tol = max(1e-5, 4.0 * max(H.rel_err(o32[0], r0), H.rel_err(o32[1], rx)))
+        assert H.rel_err(fwd["eps_hist"][0].cpu().numpy(), re[0]) <= 1e-5
+        assert H.rel_err(fwd["x0"].cpu().numpy(), r0) <= tol and H.rel_err(fwd["xt_hist"].cpu().numpy(), rx) <= tol, case.name
     got = {k: v.cpu().numpy() for k, v in _flatten(grads).items()}
     ref = _flatten(gref)
     assert set(got) == set(ref), (sorted(got), sorted(ref))
@@ -108,9 +120,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("stash", [False, True], ids=["recompute", "stash"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
-def test_vjp_matches_oracle(case):
-    _run(case)
+def test_vjp_matches_oracle(case, stash):
+    """Both backward paths: from xt_hist alone (the sweep recomputes every step) and from the training forward's stash."""
+    _run(case, stash)
 
 
 def test_vjp_unsupported_is_loud():
