@@ -27,6 +27,9 @@
 
 // One translation unit per sweep phase (-DFRL_BWD_PHASE=0|1|2, flow-rl_amd/build.py) so the three heavy instantiation sets
 // compile in parallel; the phase-0 unit also carries the prepare, dW and reduce kernels.
+#ifndef FRL_BWD_HRING
+#define FRL_BWD_HRING 8
+#endif
 #ifndef FRL_BWD_PHASE
 #error "compile with -DFRL_BWD_PHASE=<0|1|2>"
 #endif
@@ -137,9 +140,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 frl_bwd_sweep_kernel(const BArgs b) {
   typedef Geo<32> G;
   typedef f32x16 acc_t;
-  constexpr int TR = 32, H = 256, KS = 2, NR = 16, RING = 4;
+  constexpr int TR = 32, H = 256, KS = 2, NR = 16, RING = 4, HRING = FRL_BWD_HRING;
   constexpr int NB = H / TR, NG = NB / 4, GW = 4 * TR, NK = NB * NR, ROWB = H * 4, RINGL = 8, NLD = NK / 4;
   constexpr int N0 = NRX + CKMAX;
+  constexpr int ARD = 4;            // act'(z) register ring of the backward: pair rows in flight (HBM latency at one wave per SIMD)
   const KArgs& a = b.k;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,14 +190,14 @@ frl_bwd_sweep_kernel(const BArgs b) {
     sfor<NB>([&](auto BI) { constexpr int bb = decltype(BI)::value; sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; Q[bb][r] = 0.0f; }); });
   };
 
-  f32x4 ring[RING][NG];
+  f32x4 ring[HRING][NG];   // hidden-layer weight ring: HRING - 1 k-steps ahead (stores share vmcnt with loads on gfx9: the lookahead must cover a store's acknowledge)
   auto hload = [&](__amdgpu_buffer_rsrc_t rs, auto KI) {
     constexpr int k = decltype(KI)::value % NK;
     constexpr int bb = k / NR, r = k % NR;
     constexpr int soff = (GW * (bb >> 2) + (bb & 3) + 4 * G::rowr(r)) * ROWB;
     sfor<NG>([&](auto GI) {
       constexpr int g = decltype(GI)::value;
-      ring[k % RING][g] = ldw(rs, voff_h + g * (GW * 4), soff);
+      ring[k % HRING][g] = ldw(rs, voff_h + g * (GW * 4), soff);
     });
   };
   f32x4 r0[RING][NG];
@@ -244,7 +248,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
       // hidden Dense_l: consumes h_{l-1} = act(z_{l-1}) pair by pair, stashing h and act'
       for (int l = 1; l < a.L; ++l) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
-        sfor<RING - 1>([&](auto KI) { hload(rs, KI); });
+        sfor<HRING - 1>([&](auto KI) { hload(rs, KI); });
         bias_init(Q, s_bh + (l - 1) * H);
         const int drow = (l - 1) * 32768;
         float bop, bn1, bn2 = 0.0f;
@@ -256,7 +260,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
         }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
-          if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
+          if constexpr (k + HRING - 1 < NK) hload(rs, std::integral_constant<int, k + HRING - 1>{});
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
             f32x2 h, d;
             act_grad2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]}, h, d);
@@ -265,7 +269,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
           }
           sfor<NG>([&](auto GI) {
             constexpr int g = decltype(GI)::value;
-            const f32x4 aw = ring[k % RING][g];
+            const f32x4 aw = ring[k % HRING][g];
             sfor<4>([&](auto JI) { constexpr int q = decltype(JI)::value; Q[g * 4 + q] = G::mfma(aw[q], bop, Q[g * 4 + q]); });
           });
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -460,31 +464,30 @@ frl_bwd_sweep_kernel(const BArgs b) {
       // hidden layers, downwards: dL/dh_{l-1} = W_l (dL/dh_l * act'(z_l))
       for (int l = a.L - 1; l >= 1; --l) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(b.wt, l - 1), 0, H * ROWB, 0x00020000);
-        sfor<RING - 1>([&](auto KI) { hload(rs, KI); });
+        sfor<HRING - 1>([&](auto KI) { hload(rs, KI); });
         zero_init(Q);
         const int drow = l * 32768;
-        f32x2 ar[4];
-        sfor<3>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, drow + q * 512); });
+        f32x2 ar[ARD];
+        sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, drow + q * 512); });
         float bop, bn1, bn2 = 0.0f;
         {
-          ar[3] = ld2(rs_ad, voff_d, drow + 3 * 512);
           const f32x2 gz = f32x2{P[0][0], P[0][1]} * ar[0];
           st2(gz, rs_gd, voff_d, drow);
           bop = gz[0]; bn1 = gz[1];
         }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
-          if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
+          if constexpr (k + HRING - 1 < NK) hload(rs, std::integral_constant<int, k + HRING - 1>{});
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
             constexpr int rho = (k + 1) / 2;
-            if constexpr (rho + 3 < NK / 2) ar[(rho + 3) % 4] = ld2(rs_ad, voff_d, drow + (rho + 3) * 512);
-            const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % 4];
+            if constexpr (rho + ARD - 1 < NK / 2) ar[(rho + ARD - 1) % ARD] = ld2(rs_ad, voff_d, drow + (rho + ARD - 1) * 512);
+            const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % ARD];
             st2(gz, rs_gd, voff_d, drow + rho * 512);
             bn1 = gz[0]; bn2 = gz[1];
           }
           sfor<NG>([&](auto GI) {
             constexpr int g = decltype(GI)::value;
-            const f32x4 aw = ring[k % RING][g];
+            const f32x4 aw = ring[k % HRING][g];
             sfor<4>([&](auto JI) { constexpr int q = decltype(JI)::value; Q[g * 4 + q] = G::mfma(aw[q], bop, Q[g * 4 + q]); });
           });
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -500,8 +503,8 @@ frl_bwd_sweep_kernel(const BArgs b) {
       {
         f32x4 rl[RINGL];
         sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsxq, voff_l, q * 1024); });
-        f32x2 ar[4];
-        sfor<4>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, q * 512); });
+        f32x2 ar[ARD];
+        sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, q * 512); });
         float bop, bn1, bn2 = 0.0f;
         {
           const f32x2 gz = f32x2{P[0][0], P[0][1]} * ar[0];
@@ -514,8 +517,8 @@ frl_bwd_sweep_kernel(const BArgs b) {
             rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsxq, voff_l, (k / 4 + RINGL - 1) * 1024);
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
             constexpr int rho = (k + 1) / 2;
-            if constexpr (rho + 3 < NK / 2) ar[(rho + 3) % 4] = ld2(rs_ad, voff_d, (rho + 3) * 512);
-            const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % 4];
+            if constexpr (rho + ARD - 1 < NK / 2) ar[(rho + ARD - 1) % ARD] = ld2(rs_ad, voff_d, (rho + ARD - 1) * 512);
+            const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % ARD];
             st2(gz, rs_gd, voff_d, rho * 512);
             bn1 = gz[0]; bn2 = gz[1];
           }
