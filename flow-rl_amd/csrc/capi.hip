@@ -212,13 +212,13 @@ double frl_hoisted_flops(const FrlDesc* desc) {
   return 2.0 * (evals - (double)desc->n_states) * pl.C * pl.H;
 }
 
-int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
-                        void* workspace, size_t workspace_bytes, void* hip_stream) {
+static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                                void* workspace, size_t workspace_bytes, void* hip_stream, bool allow_hoist) {
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr) { set_error("params is NULL"); return FRL_EINVAL; }
   Plan pl;
-  plan_from_desc(*desc, pl);
+  plan_from_desc(*desc, pl, allow_hoist);
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
   for (int l = 0; l <= desc->n_hidden; ++l)
@@ -259,6 +259,11 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
   }
   if (rc == FRL_OK && pl.bf16) rc = launch_prepare_bf16(*params, pl, (float*)workspace, (hipStream_t)hip_stream);
   return rc;
+}
+
+int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
+                        void* workspace, size_t workspace_bytes, void* hip_stream) {
+  return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, true);
 }
 
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
@@ -382,7 +387,7 @@ static int validate_bwd(const FrlDesc* d) {
   int rc = validate_desc(d);
   if (rc != FRL_OK) return rc;
   Plan pl;
-  plan_from_desc(*d, pl);
+  plan_from_desc(*d, pl, false);       // the VJP never hoists the condition rows: they are contracted per chain
   if (pl.mode > MODE_CNF_EULER) { set_error("VJP: solvers dpm2 / dpm++2m have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->layer_norm) { set_error("VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->dtype == FRL_DTYPE_BF16) {
@@ -393,11 +398,13 @@ static int validate_bwd(const FrlDesc* d) {
     return FRL_OK;
   }
   if (pl.H != 256 || pl.TR != 32) { set_error("VJP: only the 256-wide (32x32x2) geometry has a backward kernel"); return FRL_EUNSUPPORTED; }
-  if (pl.AR > 4 || pl.CK > 12 || pl.A + pl.C > 32) { set_error("VJP: x_dim <= 8 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
-  if (d->cond_embed) { set_error("VJP: cond_embedding backward not built"); return FRL_EUNSUPPORTED; }
+  if (pl.AR > 12 || pl.CK > 64) { set_error("VJP: x_dim <= 24 and <= 128 condition rows required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
   if (d->act != FRL_ACT_MISH && d->act != FRL_ACT_SILU && d->act != FRL_ACT_RELU) { set_error("VJP: activation %d has no backward kernel (mish / silu / relu)", d->act); return FRL_EUNSUPPORTED; }
   return FRL_OK;
 }
+
+// x_dim > 8, more than 24 condition rows or a cond_embedding: the wide sweep build, which exists for the stash path only
+static bool bwd_needs_stash(const FrlDesc* d, const Plan& pl) { return d->dtype == FRL_DTYPE_F32 && (pl.AR > 4 || pl.CK > 12 || d->cond_embed); }
 
 size_t frl_bwd_workspace_bytes(const FrlDesc* desc) {
   if (validate_bwd(desc) != FRL_OK) return 0;
@@ -437,6 +444,14 @@ static void fill_bwd_args(const FrlDesc* desc, const FrlParams* params, const Pl
   b.n_ts = bf16 ? bp16.n_ts : bp.n_ts;
   b.part = ws + (bf16 ? bp16.off_part : bp.off_part);
   b.n_part = bf16 ? bp16.n_part : bp.n_part;
+  b.k0_rows = bf16 ? 32 : bp.k0_rows;
+  b.ge_stride = bf16 ? 256 : bp.ge_stride;
+  if (!bf16 && desc->cond_embed) {
+    // the predictor sees cfeat = cond_embedding(obs) (n_states, 128), computed once per state into the workspace
+    a.cond = ws + pl.off_cfeat;
+    b.ws_w0cq = ws + bp.off_w0cq;
+    b.gcf = ws + bp.off_gcf;
+  }
 }
 
 int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* bufs,
@@ -468,8 +483,15 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
   if (rng && bufs->rng_total_chains != 0 && (bufs->rng_chain_offset < 0 || bufs->rng_chain_offset + pl.B > bufs->rng_total_chains)) {
     set_error("bufs.rng_chain_offset / rng_total_chains do not cover this call's chains"); return FRL_EINVAL; }
   if (needs_noise && !rng && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step (or set desc.rng_impl and bufs.rng_key)"); return FRL_EINVAL; }
-  rc = frl_sampler_prepare(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream);
+  rc = sampler_prepare_impl(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream, false);
   if (rc != FRL_OK) return rc;
+  if (desc->cond_embed) {
+    for (int k = 0; k < 2; ++k)
+      if (params->cond_kernel[k] == nullptr || params->cond_bias[k] == nullptr) { set_error("params.cond_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+    rc = launch_cond_embed(desc->act, bufs->cond, desc->n_states, desc->cond_in_dim, params->cond_kernel[0], params->cond_bias[0],
+                           params->cond_kernel[1], params->cond_bias[1], ws + pl.off_cfeat, stream);
+    if (rc != FRL_OK) return rc;
+  }
   BArgs b;
   fill_bwd_args(desc, params, pl, bp, bp16, false, ws, bufs->cond, b);
   KArgs& a = b.k;
@@ -510,6 +532,16 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   const bool stash = bufs->have_stash != 0;
   if (stash && bf16) { set_error("have_stash: the bf16 VJP has no training forward (it recomputes)"); return FRL_EUNSUPPORTED; }
   if (stash && bufs->eps_hist == nullptr) { set_error("have_stash = 1 needs bufs.eps_hist (history[1] of frl_sampler_fwd_train)"); return FRL_EINVAL; }
+  if (!stash && bwd_needs_stash(desc, pl)) {
+    set_error("VJP: x_dim %d / %d condition rows%s: run the forward with frl_sampler_fwd_train and pass have_stash = 1 (the recompute path covers x_dim <= 8, <= 24 condition rows, no cond_embedding)",
+              pl.A, pl.C, desc->cond_embed ? " / cond_embedding" : "");
+    return FRL_EUNSUPPORTED;
+  }
+  if (desc->cond_embed)
+    for (int k = 0; k < 2; ++k) {
+      if (params->cond_kernel[k] == nullptr || params->cond_bias[k] == nullptr) { set_error("params.cond_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+      if (bufs->grad_cond_kernel[k] == nullptr || bufs->grad_cond_bias[k] == nullptr) { set_error("bufs.grad_cond_kernel/bias[%d] is NULL (desc.cond_embed = 1)", k); return FRL_EINVAL; }
+    }
   for (int l = 0; l <= desc->n_hidden; ++l) {
     if (bufs->grad_kernel[l] == nullptr) { set_error("bufs.grad_kernel[%d] is NULL", l); return FRL_EINVAL; }
     if (l > 0 && bufs->grad_bias[l] == nullptr) { set_error("bufs.grad_bias[%d] is NULL", l); return FRL_EINVAL; }
@@ -518,7 +550,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   float* ws = (float*)workspace;
   // forward tables (coefficients, tb, packed edge layers) — already there after frl_sampler_fwd_train — then the transposed images
   if (!stash) {
-    rc = frl_sampler_prepare(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream);
+    rc = sampler_prepare_impl(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream, false);
     if (rc != FRL_OK) return rc;
   }
   rc = bf16 ? launch_prepare_bwd_bf16(*params, bp16, ws, stream) : launch_prepare_bwd(*params, bp, ws, stream);
@@ -532,6 +564,13 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   b.grad_tb = bufs->grad_tb;
   rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stash ? 2 : 0, stream);
   if (rc != FRL_OK) return rc;
+  if (desc->cond_embed) {
+    // dL/dcfeat (per chain, summed over steps by the sweep) -> the two embedding layers (bufs.cond = the raw observations)
+    rc = launch_cond_embed_bwd(desc->act, bufs->cond, desc->n_states, desc->particles, desc->cond_in_dim, params->cond_kernel[0],
+                               params->cond_bias[0], params->cond_kernel[1], params->cond_bias[1], b.gcf, ws + bp.off_ceb,
+                               bufs->grad_cond_kernel[0], bufs->grad_cond_bias[0], bufs->grad_cond_kernel[1], bufs->grad_cond_bias[1], stream);
+    if (rc != FRL_OK) return rc;
+  }
   const bool native_time = (desc->time_embed == FRL_TEMB_NONE) ? (bufs->grad_bias[0] != nullptr) : (bufs->grad_tmlp_kernel[0] != nullptr);
   if (!native_time) return FRL_OK;
   if (desc->time_embed != FRL_TEMB_NONE) {

@@ -149,6 +149,116 @@ frl_state_bias_kernel(const float* __restrict__ obs, long long n_states, int S, 
   }
 }
 
+// ---- cond_embedding backward (DACER's actor loss differentiates the embedding too: dacer.py:141-162, ddpm.py:89-90) -----
+// activation and derivative in one go (the three activations the chain VJP supports)
+__device__ __forceinline__ void cact_grad(int act, float z, float& h, float& d) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  if (act == FRL_ACT_MISH) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(z, -88.0f, 20.0f) * LOG2E);
+    const float n = e * (e + 2.0f), r = __builtin_amdgcn_rcpf(n + 2.0f);
+    h = z * (n * r);
+    d = n * r + 4.0f * z * e * (e + 1.0f) * r * r;
+  } else if (act == FRL_ACT_SILU) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-z, -88.0f, 80.0f) * LOG2E);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + e);
+    h = z * sg;
+    d = h * (1.0f - sg) + sg;
+  } else {
+    h = fmaxf(z, 0.0f);
+    d = z > 0.0f ? 1.0f : 0.0f;
+  }
+}
+
+// One workgroup (128 threads = the 128 features) per STATE: recompute the two layers, sum dL/dcfeat over the state's
+// particles, chain rule down to dL/dz1; leaves h1 | dL/dz1 | dL/dz2 in scratch[state][3][128] for the reduce kernel.
+__global__ void __launch_bounds__(128)
+frl_cond_embed_bwd_state_kernel(int act, const float* __restrict__ obs, int S, int particles, const float* __restrict__ w0,
+                                const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                                const float* __restrict__ gcf, float* __restrict__ scratch) {
+  constexpr int E = COND_EMBED_DIM;
+  extern __shared__ float sm[];          // obs[S] | h1[E] | dz2[E]
+  float* s_obs = sm;
+  float* s_h1 = sm + S;
+  float* s_dz2 = s_h1 + E;
+  const long long state = blockIdx.x;
+  const int t = threadIdx.x;
+  for (int k = t; k < S; k += E) s_obs[k] = obs[state * S + k];
+  __syncthreads();
+  float z1 = b0[t];
+  for (int k = 0; k < S; ++k) z1 = fmaf(s_obs[k], w0[(size_t)k * E + t], z1);
+  float h1, a1;
+  cact_grad(act, z1, h1, a1);
+  s_h1[t] = h1;
+  __syncthreads();
+  float z2 = b1[t];
+  for (int k = 0; k < E; ++k) z2 = fmaf(s_h1[k], w1[(size_t)k * E + t], z2);
+  float h2, a2;
+  cact_grad(act, z2, h2, a2);
+  float g = 0.0f;
+  for (int p = 0; p < particles; ++p) g += gcf[((size_t)state * particles + p) * E + t];
+  const float dz2 = g * a2;
+  s_dz2[t] = dz2;
+  __syncthreads();
+  float dh1 = 0.0f;
+  for (int o = 0; o < E; ++o) dh1 = fmaf(w1[(size_t)t * E + o], s_dz2[o], dh1);
+  float* sc = scratch + (size_t)state * 3 * E;
+  sc[t] = h1;
+  sc[E + t] = dh1 * a1;
+  sc[2 * E + t] = dz2;
+}
+
+// dW0 (S, 128), db0, dW1 (128, 128), db1: one thread per element, the states added in index order on four interleaved partial
+// sums (a fixed order: bitwise reproducible).  O(n_states (S + 128) 128) — a training batch has a few hundred states.
+__global__ void __launch_bounds__(256)
+frl_cond_embed_bwd_reduce_kernel(const float* __restrict__ obs, long long n_states, int S, const float* __restrict__ scratch,
+                                 float* __restrict__ g_w0, float* __restrict__ g_b0, float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  constexpr int E = COND_EMBED_DIM;
+  const long long n0 = (long long)S * E, n1 = (long long)E * E, total = n0 + E + n1 + E;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int kind, i = 0, o;          // 0: dW0[i][o]  1: db0[o]  2: dW1[i][o]  3: db1[o]
+  long long r = e;
+  if (r < n0) { kind = 0; i = (int)(r / E); o = (int)(r % E); }
+  else if ((r -= n0) < E) { kind = 1; o = (int)r; }
+  else if ((r -= E) < n1) { kind = 2; i = (int)(r / E); o = (int)(r % E); }
+  else { kind = 3; o = (int)(r - n1); }
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (long long s = 0; s < n_states; ++s) {
+    const float* sc = scratch + (size_t)s * 3 * E;
+    float v;
+    if (kind == 0) v = obs[s * S + i] * sc[E + o];
+    else if (kind == 1) v = sc[E + o];
+    else if (kind == 2) v = sc[i] * sc[2 * E + o];
+    else v = sc[2 * E + o];
+    acc[s & 3] += v;
+  }
+  const float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (kind == 0) g_w0[e] = sum;
+  else if (kind == 1) g_b0[o] = sum;
+  else if (kind == 2) g_w1[(size_t)i * E + o] = sum;
+  else g_b1[o] = sum;
+}
+
+int launch_cond_embed_bwd(int act, const float* obs, long long n_states, int particles, int in_dim, const float* w0, const float* b0,
+                          const float* w1, const float* b1, const float* gcf, float* scratch, float* g_w0, float* g_b0, float* g_w1,
+                          float* g_b1, hipStream_t stream) {
+  if (n_states <= 0) return FRL_OK;
+  if (act != FRL_ACT_MISH && act != FRL_ACT_SILU && act != FRL_ACT_RELU) { set_error("cond_embedding backward: activation %d (mish / silu / relu)", act); return FRL_EUNSUPPORTED; }
+  const size_t lds = sizeof(float) * ((size_t)in_dim + 2 * COND_EMBED_DIM);
+  if (lds > 60000) { set_error("cond_embedding backward: observation width %d too large", in_dim); return FRL_EUNSUPPORTED; }
+  if (n_states > 0x7fffffffLL) { set_error("cond_embedding backward: too many states"); return FRL_EUNSUPPORTED; }
+  hipLaunchKernelGGL(frl_cond_embed_bwd_state_kernel, dim3((unsigned)n_states), dim3(COND_EMBED_DIM), lds, stream, act, obs, in_dim, particles,
+                     w0, b0, w1, b1, gcf, scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("cond_embed bwd launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  const long long total = (long long)in_dim * COND_EMBED_DIM + COND_EMBED_DIM + (long long)COND_EMBED_DIM * COND_EMBED_DIM + COND_EMBED_DIM;
+  hipLaunchKernelGGL(frl_cond_embed_bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, obs, n_states, in_dim,
+                     scratch, g_w0, g_b0, g_w1, g_b1);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("cond_embed bwd reduce launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
 int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, const float* w, const float* b, float* zs,
                       hipStream_t stream) {
   if (n_states <= 0) return FRL_OK;

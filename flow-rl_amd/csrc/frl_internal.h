@@ -67,26 +67,27 @@ struct Plan {
   size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
 };
 
-inline int plan_layout(const FrlDesc& d, Plan& p);
+inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist = true);
 
-inline int plan_from_desc(const FrlDesc& d, Plan& p) {
+// allow_hoist = false: the condition rows of Dense_0 stay in the kernel's operand (the chain VJP contracts them per chain)
+inline int plan_from_desc(const FrlDesc& d, Plan& p, bool allow_hoist = true) {
   p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps; p.L = d.n_hidden;
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
   p.AO = p.A; p.x_row0 = 0; p.c_row0 = p.A + p.Dp;
   p.H = d.hidden[0];
-  return plan_layout(d, p);
+  return plan_layout(d, p, allow_hoist);
 }
 
 // Second half of the plan: geometry and workspace layout from the (possibly overridden) dims above.
-inline int plan_layout(const FrlDesc& d, Plan& p) {
+inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist) {
   p.TR = (p.H <= 256) ? 32 : 16;
   p.KS = (p.TR == 32) ? 2 : 4;
   p.NR = (p.TR == 32) ? 16 : 4;
   p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
   p.AR = p.XR / p.KS;
   p.CK = (p.C + p.KS - 1) / p.KS;
-  p.hoist = (d.dtype == FRL_DTYPE_F32 && p.C > 0 && ((d.particles >= 4 && p.C >= 32) || p.CK > (p.TR == 32 ? 64 : 12))) ? 1 : 0;
+  p.hoist = (allow_hoist && d.dtype == FRL_DTYPE_F32 && p.C > 0 && ((d.particles >= 4 && p.C >= 32) || p.CK > (p.TR == 32 ? 64 : 12))) ? 1 : 0;
   if (p.hoist) p.CK = 0;
   p.K0p = p.XR + p.KS * p.CK;
   p.merged = (p.K0p <= SLAB_ROWS) ? 1 : 0;
@@ -167,15 +168,15 @@ inline size_t time_bwd_scratch_floats(int T, int D) { return 2 * ((size_t)T * (1
 //   Ad = act'(z_l)  (re-read by the backward sweep)
 //   Gd = dL/dz_l    (the G operand of dW_l)
 // Deterministic weight-gradient reduction (no float atomics): workgroup w of the dW kernels owns slot w of `part`, a
-// [n_part][dw_part_stride] image of its partial sums — Dense_0 tile [32 staged rows][256], hidden tiles [256][256],
+// [n_part][dw_part_stride] image of its partial sums — Dense_0 tile [k0_rows staged rows x | cond][256] (k0_rows = 32 or 160), hidden tiles [256][256],
 // Dense_L tile [256][32], bias column sums [L][256] (layers 1..L), per-step dL/dtb [T][256] — and a second kernel
 // (frl_bwd_reduce_kernel) adds the slots in slot order, writing every gradient leaf exactly once.
 struct DwPart {
   size_t k0, kh, kl, bias, tb, stride;   // float offsets inside one slot; kh is hidden layer 1 (layer l at kh + (l-1) 65536)
 };
-__host__ __device__ inline DwPart dw_part_layout(int L, int T) {
+__host__ __device__ inline DwPart dw_part_layout(int L, int T, int k0_rows = 32) {
   DwPart d;
-  d.k0 = 0; d.kh = 8192; d.kl = d.kh + (size_t)(L - 1) * 65536; d.bias = d.kl + 8192; d.tb = d.bias + (size_t)L * 256;
+  d.k0 = 0; d.kh = (size_t)k0_rows * 256; d.kl = d.kh + (size_t)(L - 1) * 65536; d.bias = d.kl + 8192; d.tb = d.bias + (size_t)L * 256;
   d.stride = d.tb + (size_t)T * 256;
   return d;
 }
@@ -184,6 +185,13 @@ inline int device_cus();
 struct BwdPlan {
   Plan f;
   int n_part; size_t off_part;   // dW partial slots (= workgroups of the dW kernel)
+  int cond_embed;                // desc.cond_embed
+  int wide;                      // 1: the <12, 64> operand build (x_dim <= 24, <= 128 condition rows): DACER / QVPO shapes
+  int k0_rows;                   // staged rows of Dense_0's dW tile: 32 ceil((A + C) / 32)
+  int ge_stride;                 // floats of dL/deps per tile-step: 64 x (4 | 12) registers
+  size_t off_w0cq;               // per-lane packed images of Dense_0's cond rows, 4 blocks of 32 features (cond_embed only)
+  size_t off_gcf;                // dL/dcfeat per CHAIN, (B, 128), summed over steps (cond_embed only)
+  size_t off_ceb;                // cond_embedding backward scratch: (n_states, 3, 128) = h1 | dL/dz1 | dL/dz2
   long long n_wt, n_ts;          // wave tiles (32 chains), tile-steps
   size_t off_wt[FRL_MAX_HIDDEN - 1];   // transposed hidden kernels WT_l[out][in]
   size_t off_wlt;                // transposed, row-padded last kernel  [XR][H]
@@ -195,8 +203,13 @@ struct BwdPlan {
 };
 
 inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
-  plan_from_desc(d, b.f);
+  plan_from_desc(d, b.f, false);
   const Plan& p = b.f;
+  b.cond_embed = d.cond_embed ? 1 : 0;
+  b.wide = (p.AR > 4 || p.CK > 12) ? 1 : 0;
+  b.k0_rows = 32 * ((p.A + p.C + 31) / 32);
+  if (b.k0_rows < 32) b.k0_rows = 32;
+  b.ge_stride = 64 * (b.wide ? 12 : 4);
   b.n_wt = (p.B + 31) / 32;
   b.n_ts = b.n_wt * p.T;
   size_t o = p.total_floats;
@@ -207,10 +220,13 @@ inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
   b.off_hd = take((size_t)b.n_ts * p.L * 8192);
   b.off_ad = take((size_t)b.n_ts * p.L * 8192);
   b.off_gd = take((size_t)b.n_ts * p.L * 8192);
-  b.off_ge = take((size_t)b.n_ts * 256);
+  b.off_ge = take((size_t)b.n_ts * b.ge_stride);
   b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
   { const long long cus = device_cus(); b.n_part = (int)(b.n_ts < cus ? b.n_ts : cus); if (b.n_part < 1) b.n_part = 1; }
-  b.off_part = take((size_t)b.n_part * dw_part_layout(p.L, p.T).stride);
+  b.off_part = take((size_t)b.n_part * dw_part_layout(p.L, p.T, b.k0_rows).stride);
+  b.off_w0cq = take(d.cond_embed ? (size_t)4 * p.H * 64 : 0);
+  b.off_gcf = take(d.cond_embed ? (size_t)p.B * COND_EMBED_DIM : 0);
+  b.off_ceb = take(d.cond_embed ? (size_t)d.n_states * 3 * COND_EMBED_DIM : 0);
   b.total_floats = o;
   return 0;
 }
@@ -226,7 +242,14 @@ struct BArgs {
   int Dp;                         // time rows of Dense_0 (skipped by the dW_0 scatter)
   long long n_ts;
   float* part; int n_part;        // dW partial slots (DwPart layout), one per workgroup of the dW kernel
+  int k0_rows, ge_stride;         // BwdPlan.k0_rows / ge_stride
+  const float* ws_w0cq;           // packed Dense_0 cond rows (4 blocks), or NULL
+  float* gcf;                     // (B, 128) dL/dcfeat per chain, or NULL: written by the backward sweep of the wide build
 };
+// cond_embedding backward (csrc/cond_embed.hip): per-state chain rule, then a fixed-order sum over the states
+int launch_cond_embed_bwd(int act, const float* obs, long long n_states, int particles, int in_dim, const float* w0, const float* b0,
+                          const float* w1, const float* b1, const float* gcf, float* scratch, float* g_w0, float* g_b0, float* g_w1,
+                          float* g_b1, hipStream_t stream);
 int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order second stage of the weight-gradient reduction
 
 // ---- backward, bf16-MFMA variant (csrc/sampler_bwd_bf16.hip) -------------------------------------------------

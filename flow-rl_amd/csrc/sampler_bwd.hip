@@ -82,7 +82,8 @@ struct PBArgs {
   const float* kernel[FRL_MAX_HIDDEN + 1];
   float* wt[FRL_MAX_HIDDEN - 1];
   float* wlt; float* w0xq;
-  int H, L, A, XR;
+  float* w0cq;               // [4 blocks][H * 64]: Dense_0's cond rows 32 m .. 32 m + 31 as A operands (dL/dcfeat), or NULL
+  int H, L, A, XR, C, c_row0;
 };
 
 __global__ void __launch_bounds__(256) frl_bwd_prepare_kernel(const PBArgs p) {
@@ -111,7 +112,10 @@ __global__ void __launch_bounds__(256) frl_bwd_prepare_kernel(const PBArgs p) {
     const int k = 4 * q + e, blk = k / 16, r = k - blk * 16;
     const int i = lane & 31, sl = lane >> 5;
     const int kf = 128 * (blk >> 2) + (blk & 3) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * sl);
-    p.w0xq[idx] = (i < p.A) ? W0[(size_t)i * H + kf] : 0.0f;
+    p.w0xq[idx] = (i < p.A && kf < H) ? W0[(size_t)i * H + kf] : 0.0f;
+    if (p.w0cq != nullptr)
+      for (int m = 0; m < 4; ++m)
+        p.w0cq[(size_t)m * H * 64 + idx] = (32 * m + i < p.C && kf < H) ? W0[(size_t)(p.c_row0 + 32 * m + i) * H + kf] : 0.0f;
   }
 }
 
@@ -120,7 +124,8 @@ int launch_prepare_bwd(const FrlParams& prm, const BwdPlan& bp, float* ws, hipSt
   for (int l = 0; l <= bp.f.L; ++l) p.kernel[l] = prm.kernel[l];
   for (int l = 1; l < bp.f.L; ++l) p.wt[l - 1] = ws + bp.off_wt[l - 1];
   p.wlt = ws + bp.off_wlt; p.w0xq = ws + bp.off_w0xq;
-  p.H = bp.f.H; p.L = bp.f.L; p.A = bp.f.A; p.XR = bp.f.XR;
+  p.w0cq = bp.cond_embed ? ws + bp.off_w0cq : nullptr;
+  p.H = bp.f.H; p.L = bp.f.L; p.A = bp.f.A; p.XR = bp.f.XR; p.C = bp.f.C; p.c_row0 = bp.f.c_row0;
   hipLaunchKernelGGL(frl_bwd_prepare_kernel, dim3(256), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("bwd prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
@@ -140,7 +145,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 frl_bwd_sweep_kernel(const BArgs b) {
   typedef Geo<32> G;
   typedef f32x16 acc_t;
-  constexpr int TR = 32, H = 256, KS = 2, NR = 16, RING = 4, HRING = FRL_BWD_HRING;
+  constexpr int TR = 32, H = 256, KS = 2, NR = 16, RING = 4, HRING = (NRX > 4) ? 4 : FRL_BWD_HRING;   // the wide build trades ring depth for operand registers
+  constexpr bool WIDE = NRX > 4;
   constexpr int NB = H / TR, NG = NB / 4, GW = 4 * TR, NK = NB * NR, ROWB = H * 4, RINGL = 8, NLD = NK / 4;
   constexpr int N0 = NRX + CKMAX;
   constexpr int ARD = 4;            // act'(z) register ring of the backward: pair rows in flight (HBM latency at one wave per SIMD)
@@ -378,6 +384,11 @@ frl_bwd_sweep_kernel(const BArgs b) {
         if (valid && ai < a.A) a.x0[chain * a.A + ai] = xs[r];
       });
     } else {
+    // wide build with a cond_embedding: dL/dcfeat[chain] = sum over steps of W0[cond rows] dL/dz_0, four 32-feature blocks
+    // that stay in accumulators over the whole step loop
+    acc_t OC[WIDE ? 4 : 1];
+    if constexpr (WIDE) sfor<4>([&](auto MI) { sfor<NR>([&](auto RI) { OC[decltype(MI)::value][decltype(RI)::value] = 0.0f; }); });
+    const bool dcond = WIDE && b.gcf != nullptr;
     float gx[NRX];      // dL/dx_{j+1}, same register layout as the chain state
     sfor<NRX>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
@@ -445,7 +456,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
         const bool in = valid && ai < a.A;
         ge[r] = in ? g_e : 0.0f;
         gxd[r] = in ? g_x : 0.0f;
-        b.ge[(size_t)ts * 256 + r * 64 + lane] = ge[r];
+        b.ge[(size_t)ts * b.ge_stride + r * 64 + lane] = ge[r];
       });
 
       // ================= backward through the net ==================================================================
@@ -503,6 +514,9 @@ frl_bwd_sweep_kernel(const BArgs b) {
       {
         f32x4 rl[RINGL];
         sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsxq, voff_l, q * 1024); });
+        f32x4 rc[WIDE ? 4 : 1][2];       // cond-row operands: one 16-byte load = 4 k-steps, requested 4 k-steps ahead
+        const __amdgpu_buffer_rsrc_t rscq = __builtin_amdgcn_make_buffer_rsrc((void*)(WIDE && b.ws_w0cq != nullptr ? b.ws_w0cq : b.ws_w0xq), 0, (WIDE ? 4 : 1) * H * 64 * 4, 0x00020000);   // image m at m * H * 64 floats (the first NK * 64 of each are read)
+        if constexpr (WIDE) { if (dcond) sfor<4>([&](auto MI) { constexpr int m = decltype(MI)::value; rc[m][0] = ldw(rscq, voff_l + m * (H * 64 * 4), 0); }); }
         f32x2 ar[ARD];
         sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, q * 512); });
         float bop, bn1, bn2 = 0.0f;
@@ -523,6 +537,13 @@ frl_bwd_sweep_kernel(const BArgs b) {
             bn1 = gz[0]; bn2 = gz[1];
           }
           OX = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, OX);
+          if constexpr (WIDE) {
+            if (dcond) {
+              if constexpr ((k & 3) == 0 && k / 4 + 1 < NLD)
+                sfor<4>([&](auto MI) { constexpr int m = decltype(MI)::value; rc[m][(k / 4 + 1) & 1] = ldw(rscq, voff_l + m * (H * 64 * 4), (k / 4 + 1) * 1024); });
+              sfor<4>([&](auto MI) { constexpr int m = decltype(MI)::value; OC[m] = G::mfma(rc[m][(k / 4) & 1][k & 3], bop, OC[m]); });
+            }
+          }
           bop = bn1; bn1 = bn2;
         });
       }
@@ -538,6 +559,12 @@ frl_bwd_sweep_kernel(const BArgs b) {
         const int ai = G::rowr(r) + 4 * ls;
         if (valid && ai < a.A) b.g_xT[chain * a.A + ai] = gx[r];
       });
+    }
+    if constexpr (WIDE) {
+      if (dcond && valid) {        // accumulator register r of block m, lane group s <-> cond feature 32 m + ROWR(r) + 4 s
+        sfor<4>([&](auto MI) { constexpr int m = decltype(MI)::value; sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value;
+          b.gcf[chain * COND_EMBED_DIM + 32 * m + G::rowr(r) + 4 * ls] = OC[m][r]; }); });
+      }
     }
     }   // PHASE != 1
   }
@@ -558,7 +585,7 @@ __device__ __forceinline__ int stash_feature(int row2, int e, int lane) {
 // Pipeline: the stash blocks of tile-step u + 1 are fetched into registers while tile-step u is contracted, staged into the
 // other half of a double-buffered LDS tile pair, one barrier per tile-step.  A workgroup owns a contiguous STEP-MAJOR range
 // of tile-steps (u = j * n_wt + wt), so the per-step column sums that make dL/dtb stay in a register between flushes.
-template <int KIND>   // 0: Dense_0 (X = [x_j ; cond], one 32-row block)  1: hidden  2: Dense_L (G = dL/deps, one block)
+template <int KIND, int NM0 = 1>   // 0: Dense_0 (X = [x_j ; cond], NM0 32-row blocks)  1: hidden  2: Dense_L (G = dL/deps, one block)
 __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* smem, long long u0, long long u1, long long n_wt) {
   constexpr int H = 256, LDP = 33, TILE = H * LDP;
   const KArgs& a = b.k;
@@ -566,7 +593,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;       // 8 waves: 4 (X blocks 2 wm, 2 wm + 1) x 2 (G blocks 4 wn .. 4 wn + 3)
   const int A = a.A, C = a.C, T = a.T, L = a.L;
-  constexpr int NM = (KIND == 1) ? 2 : 1, NN = (KIND == 1) ? 4 : 1;
+  constexpr int NM = (KIND == 1) ? 2 : (KIND == 0 ? NM0 : 1), NN = (KIND == 1) ? 4 : 1;
   const int mb0 = (KIND == 1) ? 2 * wm : (KIND == 2 ? wave : 0);
   const int nb0 = (KIND == 1) ? 4 * wn : (KIND == 0 ? wave : 0);
 
@@ -575,7 +602,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
     acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
   float bsum = 0.0f;                                   // column sum of G for feature `tid` (bias gradient)
   int jcur = -1;
-  const DwPart dp = dw_part_layout(L, T);
+  const DwPart dp = dw_part_layout(L, T, b.k0_rows);
   float* slot = b.part + (size_t)blockIdx.x * dp.stride;   // this workgroup's partial sums (deterministic second stage adds the slots)
   if constexpr (KIND == 0) {
     // per-step dL/dtb rows: a workgroup's tile-steps cover a few consecutive steps; the other rows of its slot are zero
@@ -588,13 +615,14 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
   }
 
   f32x2 xr[8], gr[8];       // staging registers: 64 pair rows / 8 waves
-  float xv[2], gv = 0.0f;
+  float xv[2 * NM0], gv[2] = {0.0f, 0.0f};
+  const int nge = b.ge_stride >> 6;      // dL/deps registers per lane in the stash (4 | 12)
   auto fetch = [&](long long u) {
     const int j = (int)(u / n_wt);
     const long long wt = u - (long long)j * n_wt, ts = wt * T + j;
     const size_t srow = (size_t)ts * L * 8192;
     if constexpr (KIND == 0) {
-      sfor<2>([&](auto EI) {
+      sfor<2 * NM0>([&](auto EI) {
         constexpr int k = decltype(EI)::value;
         const int idx = tid + 512 * k, row = idx >> 5, c = idx & 31;
         const long long chain = wt * 32 + c;
@@ -610,7 +638,8 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
       sfor<8>([&](auto QI) { constexpr int q = decltype(QI)::value; xr[q] = *(const f32x2*)(src + ((size_t)(wave + 8 * q) * 64 + lane) * 2); });
     }
     if constexpr (KIND == 2) {
-      if (wave < 4) gv = b.ge[(size_t)ts * 256 + wave * 64 + lane];
+      if (wave < nge) gv[0] = b.ge[(size_t)ts * b.ge_stride + wave * 64 + lane];
+      if (wave + 8 < nge) gv[1] = b.ge[(size_t)ts * b.ge_stride + (wave + 8) * 64 + lane];
     } else {
       const float* src = b.gd + srow + (size_t)lam * 8192;
       sfor<8>([&](auto QI) { constexpr int q = decltype(QI)::value; gr[q] = *(const f32x2*)(src + ((size_t)(wave + 8 * q) * 64 + lane) * 2); });
@@ -620,7 +649,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
     float* sX = buf;
     float* sG = buf + TILE;
     if constexpr (KIND == 0) {
-      sfor<2>([&](auto EI) { constexpr int k = decltype(EI)::value; const int idx = tid + 512 * k; sX[(idx >> 5) * LDP + (idx & 31)] = xv[k]; });
+      sfor<2 * NM0>([&](auto EI) { constexpr int k = decltype(EI)::value; const int idx = tid + 512 * k; sX[(idx >> 5) * LDP + (idx & 31)] = xv[k]; });
     } else {
       sfor<8>([&](auto QI) {
         constexpr int q = decltype(QI)::value;
@@ -630,7 +659,8 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
       });
     }
     if constexpr (KIND == 2) {
-      if (wave < 4) sG[((wave & 3) + 8 * (wave >> 2) + 4 * lh) * LDP + li] = gv;   // register r = wave: action row ROWR(r) + 4 s
+      if (wave < nge) sG[((wave & 3) + 8 * (wave >> 2) + 4 * lh) * LDP + li] = gv[0];   // register r = wave: action row ROWR(r) + 4 s
+      if (wave + 8 < nge) sG[((wave & 3) + 8 * ((wave + 8) >> 2) + 4 * lh) * LDP + li] = gv[1];
     } else {
       sfor<8>([&](auto QI) {
         constexpr int q = decltype(QI)::value;
@@ -711,7 +741,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
 __global__ void __launch_bounds__(256) frl_bwd_reduce_kernel(const BArgs b) {
   const KArgs& a = b.k;
   const int A = a.A, C = a.C, T = a.T, L = a.L, Dp = b.Dp, H = 256;
-  const DwPart dp = dw_part_layout(L, T);
+  const DwPart dp = dw_part_layout(L, T, b.k0_rows);
   const long long n0 = (long long)(A + Dp + C) * H, nh = (long long)(L - 1) * 65536, nl = (long long)H * A;
   const long long nb = (long long)(L - 1) * H + A, ntb = (long long)T * H;
   const long long total = n0 + nh + nl + nb + ntb;
@@ -774,7 +804,8 @@ frl_bwd_dw_kernel(const BArgs b) {
   const long long n_wt = (a.B + 31) / 32;
   const long long U = n_wt * a.T;                         // tile-steps, step-major: u = j * n_wt + wt
   const long long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
-  dw_layer_f32<0>(b, 0, smem_dw, u0, u1, n_wt);
+  if (b.k0_rows <= 32) dw_layer_f32<0, 1>(b, 0, smem_dw, u0, u1, n_wt);
+  else dw_layer_f32<0, 5>(b, 0, smem_dw, u0, u1, n_wt);      // DACER / QVPO shapes: x (<= 24) | cond (<= 128) rows = up to 5 blocks
   for (int lam = 1; lam < a.L; ++lam) dw_layer_f32<1>(b, lam, smem_dw, u0, u1, n_wt);
   dw_layer_f32<2>(b, a.L, smem_dw, u0, u1, n_wt);
 }
@@ -782,15 +813,27 @@ frl_bwd_dw_kernel(const BArgs b) {
 #endif  // FRL_BWD_PHASE == 0
 
 // ---- launcher ---------------------------------------------------------------------------------------------------
-template <int ACT>
-static int launch_sweep(const BArgs& b, int grid, int block, size_t lds, hipStream_t stream) {
-  auto kern = frl_bwd_sweep_kernel<ACT, 4, 12, FRL_BWD_PHASE>;
+template <int ACT, int NRX, int CKMAX>
+static int launch_sweep_inst(const BArgs& b, int grid, int block, size_t lds, hipStream_t stream) {
+  auto kern = frl_bwd_sweep_kernel<ACT, NRX, CKMAX, FRL_BWD_PHASE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bwd sweep launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
+}
+
+// narrow operands (x_dim <= 8, <= 24 condition rows: DQL / DAC / FQL) or the wide build (x_dim <= 24, <= 128 condition rows:
+// DACER / QVPO with their cond_embedding) — the wide build exists for the training forward and the stash backward only
+template <int ACT>
+static int launch_sweep(const BArgs& b, int grid, int block, size_t lds, hipStream_t stream) {
+  if (b.k.AR <= 4 && b.k.CK <= 12) return launch_sweep_inst<ACT, 4, 12>(b, grid, block, lds, stream);
+#if FRL_BWD_PHASE != 0
+  if (b.k.AR <= 12 && b.k.CK <= 64) return launch_sweep_inst<ACT, 12, 64>(b, grid, block, lds, stream);
+#endif
+  set_error("VJP: x_dim %d / cond_dim %d: this path needs the training forward (frl_sampler_fwd_train) and its stash", b.k.A, b.k.C);
+  return FRL_EUNSUPPORTED;
 }
 
 template <>

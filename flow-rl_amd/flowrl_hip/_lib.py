@@ -59,7 +59,7 @@ class FrlBwdBufs(C.Structure):
     _fields_ = [("xt_hist", _fp), ("cond", _fp), ("g_x0", _fp), ("g_xT", _fp),
                 ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_tb", _fp),
                 ("grad_tmlp_kernel", _fp * 2), ("grad_tmlp_bias", _fp * 2), ("grad_time_kernel", _fp),
-                ("eps_hist", _fp), ("have_stash", C.c_int32)]
+                ("eps_hist", _fp), ("have_stash", C.c_int32), ("grad_cond_kernel", _fp * 2), ("grad_cond_bias", _fp * 2)]
 
 
 class FrlCriticDesc(C.Structure):

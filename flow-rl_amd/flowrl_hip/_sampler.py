@@ -438,6 +438,15 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
             grads["time_embedding"] = {"kernel": gw}
             bufs.grad_time_kernel = gw.data_ptr()
 
+    if network.cond_embedding is not None:      # DACER differentiates the embedding too (dacer.py:141-162)
+        grads["cond_embedding"] = {}
+        for i in range(2):
+            k = params["cond_embedding"][f"Dense_{i}"]
+            gk = torch.empty_like(k["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
+            gb = torch.empty_like(k["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
+            grads["cond_embedding"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
+            bufs.grad_cond_kernel[i], bufs.grad_cond_bias[i] = gk.data_ptr(), gb.data_ptr()
+
     need = lib.frl_bwd_workspace_bytes(C.byref(desc))
     if need == 0:   # invalid / unsupported descriptor: let the entry point say why
         _lib.check(lib.frl_sampler_bwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs), None, 0, None))

@@ -206,9 +206,13 @@ int frl_sampler_fwd_static(const FrlDesc* desc, const FrlParams* params, const F
  * predictor MLP and dL/dxT.  The batch-invariant time branch (O(T * D^2) work) hangs off grad_tb
  * (dL/d(tb), tb[j] = bias_0 + tfeat[j] @ kernel_0[A:A+D']): either the caller differentiates it from grad_tb (a JAX
  * binding gets that from jax.vjp of its own tfeat function) or the library does, see the optional outputs below.
- * This build: DDPM / ContinuousDDPM / CNF update rules, 256-wide predictor, mish / silu / relu, x_dim <= 8
- * (FRL_DTYPE_F32) or <= 16 (FRL_DTYPE_BF16: bf16 operands in every contraction, f32 accumulation),
- * x_dim + cond_dim <= 32, no cond_embedding; everything else returns FRL_EUNSUPPORTED. */
+ * This build: DDPM / ContinuousDDPM / CNF update rules (ddpm, ddim, Euler), 256-wide predictor, mish / silu / relu.
+ *   FRL_DTYPE_F32: x_dim <= 8 and <= 24 condition rows from xt_hist alone (the backward recomputes each step) or from
+ *     the stash of frl_sampler_fwd_train; x_dim <= 24, <= 128 condition rows and a cond_embedding MLP (DACER / QVPO
+ *     humanoid: act 17, obs 376 -> 128) through frl_sampler_fwd_train + have_stash only.
+ *   FRL_DTYPE_BF16 (bf16 operands in every contraction, f32 accumulation): x_dim <= 16, x_dim + cond_dim <= 32, no
+ *     cond_embedding, recompute path.
+ * Everything else returns FRL_EUNSUPPORTED. */
 typedef struct FrlBwdBufs {
   const float* xt_hist; /* (T, B, A) history[0] of the forward call                                     */
   const float* cond;    /* (n_states, C) as in the forward call                                         */
@@ -229,6 +233,10 @@ typedef struct FrlBwdBufs {
    * stash (act(z), act'(z) of every layer) and eps_hist instead of recomputing every step from xt_hist. */
   const float* eps_hist; /* (T, B, A) history[1] of that forward call, or NULL */
   int32_t have_stash;    /* 1: the workspace holds the stash of frl_sampler_fwd_train for the same desc / params / inputs */
+  /* desc.cond_embed = 1 (DACER's actor loss, dacer.py:141-162, differentiates the cond_embedding too): dL/d
+   * cond_embedding/Dense_{0,1} kernel (cond_in_dim, 128), (128, 128) and bias (128,); required then, OVERWRITTEN */
+  float* grad_cond_kernel[2];
+  float* grad_cond_bias[2];
 } FrlBwdBufs;
 
 size_t frl_bwd_workspace_bytes(const FrlDesc* desc);

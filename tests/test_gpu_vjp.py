@@ -120,6 +120,29 @@ CASES = [
 ]
 
 
+# DACER / QVPO shapes (dacer.py:141-162 differentiates ContinuousDDPM.sample with its cond_embedding): the wide operand build,
+# which exists for the training forward + stash backward; the recompute path must refuse them loudly
+WIDE_CASES = [
+    H.Case("dacer_humanoid", "cddpm", A=17, S=376, T=20, B=3 * 16, particles=16, temb="learnable_fourier", schedule="cosine",
+           cond_embed=True, seed=20),
+    H.Case("dacer_batch_p1", "cddpm", A=17, S=376, T=20, B=70, temb="learnable_fourier", schedule="cosine", cond_embed=True, seed=21),
+    H.Case("embed_small_act", "cddpm", A=6, S=17, T=8, B=40, temb="learnable_fourier", schedule="cosine", cond_embed=True, act="silu", seed=22),
+    H.Case("wide_cond_no_embed", "ddpm", A=17, S=128, T=5, B=64, seed=23),
+    H.Case("wide_x_only", "ddpm", A=12, S=11, T=5, B=50, act="relu", seed=24),
+    H.Case("embed_cnf", "cnf", A=8, S=39, T=6, B=2 * 8, particles=8, clip=False, cond_embed=True, seed=25),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: c.name)
+def test_vjp_wide_shapes_from_the_stash(case):
+    import flowrl_hip as fh
+    _run(case, True)
+    params, xT, cond, noise = H.make_inputs(case)
+    g = np.zeros((case.B, case.A), np.float32)
+    with pytest.raises(fh.FlowRLHipUnsupported):       # from xt_hist alone: no wide recompute build
+        product_vjp(case, H.product_model(case, params), xT, cond, noise, g, stash=False)
+
+
 @pytest.mark.parametrize("stash", [False, True], ids=["recompute", "stash"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
 def test_vjp_matches_oracle(case, stash):
