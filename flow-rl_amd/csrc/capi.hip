@@ -706,6 +706,159 @@ int frl_random_gumbel(const uint32_t* key, int32_t impl, int64_t n, float* out, 
   return launch_random_fill(key, impl, n, out, 2, (hipStream_t)hip_stream);
 }
 
+int frl_random_uniform(const uint32_t* key, int32_t impl, int64_t n, float minval, float maxval, float* out, void* hip_stream) {
+  return launch_random_uniform(key, impl, n, minval, maxval, out, (hipStream_t)hip_stream);
+}
+int frl_random_randint(const uint32_t* key, int32_t impl, int64_t n, int32_t minval, int32_t maxval, int32_t* out, void* hip_stream) {
+  return launch_random_randint(key, impl, n, minval, maxval, out, (hipStream_t)hip_stream);
+}
+
+// ---- per-sample-time network evaluation ----------------------------------------------------------
+// The network as the MODE_EVAL kernel sees it: inputs = the x rows only; the time and condition rows of Dense_0 arrive as a
+// per-sample accumulator init row (frl_time_rows_kernel + frl_state_bias_kernel).
+struct EvalPlan {
+  FrlDesc d;        // carrier descriptor of the MFMA kernel
+  Plan pl;
+  int Dp, C;        // time rows / condition rows of Dense_0
+  size_t off_cfeat, off_u, off_zt, total_floats;
+};
+
+static int eval_plan(const FrlDesc* desc, EvalPlan& e) {
+  int rc = validate_desc(desc);
+  if (rc != FRL_OK) return rc;
+  if (desc->dtype != FRL_DTYPE_F32) { set_error("frl_net_eval: f32 only"); return FRL_EUNSUPPORTED; }
+  memset(&e.d, 0, sizeof(e.d));
+  FrlDesc& d = e.d;
+  d.abi_version = FRL_ABI_VERSION;
+  d.kind = FRL_KIND_CNF; d.solver = FRL_SOLVER_EULER; d.steps = 1;     // carrier only: the mode is overridden below
+  d.n_states = (int64_t)desc->n_states * desc->particles; d.particles = 1;
+  d.x_dim = desc->x_dim; d.cond_dim = 0;
+  d.time_embed = FRL_TEMB_NONE;
+  d.n_hidden = desc->n_hidden;
+  for (int l = 0; l < FRL_MAX_HIDDEN; ++l) d.hidden[l] = desc->hidden[l];
+  d.act = desc->act; d.dtype = FRL_DTYPE_F32; d.layer_norm = desc->layer_norm; d.tile_policy = desc->tile_policy;
+  rc = validate_desc(&d);
+  if (rc != FRL_OK) return rc;
+  Plan& pl = e.pl;
+  pl.A = d.x_dim; pl.C = 0; pl.T = 1; pl.L = d.n_hidden; pl.D = 0; pl.Dp = 0;
+  pl.AO = d.x_dim; pl.x_row0 = 0; pl.c_row0 = 0;
+  pl.H = d.hidden[0];
+  plan_layout(d, pl);
+  pl.mode = MODE_EVAL;
+  if (pl.H % 128 != 0) { set_error("frl_net_eval: hidden width %d is not a multiple of 128", pl.H); return FRL_EUNSUPPORTED; }
+  e.Dp = desc->time_embed == FRL_TEMB_NONE ? 1 : desc->time_dim;
+  e.C = desc->cond_dim;
+  size_t o = pl.total_floats;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+  e.off_cfeat = take(desc->cond_embed ? (size_t)desc->n_states * COND_EMBED_DIM : 0);
+  e.off_u = take((size_t)pl.B * (e.Dp + e.C));
+  e.off_zt = take((size_t)pl.B * pl.H);
+  e.total_floats = o;
+  return FRL_OK;
+}
+
+size_t frl_net_eval_workspace_bytes(const FrlDesc* desc) {
+  EvalPlan e;
+  if (eval_plan(desc, e) != FRL_OK) return 0;
+  return e.total_floats * sizeof(float);
+}
+
+int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* workspace, size_t workspace_bytes,
+                 void* hip_stream) {
+  EvalPlan e;
+  int rc = eval_plan(desc, e);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
+  const Plan& pl = e.pl;
+  if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (workspace_bytes < e.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B", workspace_bytes, e.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  if (pl.B == 0) return FRL_OK;
+  if (bufs->x == nullptr || bufs->t == nullptr || bufs->out == nullptr) { set_error("bufs.x / t / out is NULL"); return FRL_EINVAL; }
+  if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
+  for (int l = 0; l <= desc->n_hidden; ++l)
+    if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->time_embed != FRL_TEMB_NONE) {
+    for (int k = 0; k < 2; ++k)
+      if (params->tmlp_kernel[k] == nullptr || params->tmlp_bias[k] == nullptr) { set_error("params.tmlp_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+    if (desc->time_embed == FRL_TEMB_FOURIER && params->time_kernel == nullptr) { set_error("params.time_kernel is NULL"); return FRL_EINVAL; }
+    if ((size_t)desc->time_dim * 12 * sizeof(float) > 60000) { set_error("time_dim %d too large", desc->time_dim); return FRL_EUNSUPPORTED; }
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  float* ws = (float*)workspace;
+  // packed x rows of Dense_0, Dense_L, tb = bias_0 (no time rows in the carrier plan)
+  PArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  for (int l = 0; l <= pl.L; ++l) { pa.p.kernel[l] = params->kernel[l]; pa.p.bias[l] = params->bias[l]; }
+  pa.ws = ws; pa.plan = pl; pa.kind = FRL_KIND_CNF; pa.time_embed = FRL_TEMB_NONE;
+  rc = launch_prepare(pa, stream);
+  if (rc != FRL_OK) return rc;
+  if (desc->layer_norm) {
+    float* ln = ws + pl.off_ln;
+    for (int l = 0; l < pl.L; ++l) {
+      if (params->ln_scale[l] == nullptr || params->ln_bias[l] == nullptr) { set_error("params.ln_scale/ln_bias[%d] is NULL (desc.layer_norm = 1)", l); return FRL_EINVAL; }
+      hipError_t er = hipMemcpyAsync(ln + (size_t)(2 * l) * pl.H, params->ln_scale[l], pl.H * sizeof(float), hipMemcpyDeviceToDevice, stream);
+      if (er == hipSuccess) er = hipMemcpyAsync(ln + (size_t)(2 * l + 1) * pl.H, params->ln_bias[l], pl.H * sizeof(float), hipMemcpyDeviceToDevice, stream);
+      if (er != hipSuccess) { set_error("LayerNorm rows: %s", hipGetErrorString(er)); return FRL_EHIP; }
+    }
+  }
+  const float* cond = bufs->cond;
+  if (desc->cond_embed) {
+    for (int k = 0; k < 2; ++k)
+      if (params->cond_kernel[k] == nullptr || params->cond_bias[k] == nullptr) { set_error("params.cond_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+    rc = launch_cond_embed(desc->act, bufs->cond, desc->n_states, desc->cond_in_dim, params->cond_kernel[0], params->cond_bias[0],
+                           params->cond_kernel[1], params->cond_bias[1], ws + e.off_cfeat, stream);
+    if (rc != FRL_OK) return rc;
+    cond = ws + e.off_cfeat;
+  }
+  // u[b] = [tfeat(t_b) | cond(state(b))]; zt[b] = u[b] @ kernel_0[A:]  (bias_0 is in tb)
+  rc = launch_time_rows(*desc, *params, bufs->t, cond, e.C, ws + e.off_u, pl.B, stream);
+  if (rc != FRL_OK) return rc;
+  rc = launch_state_bias(ws + e.off_u, pl.B, e.Dp + e.C, pl.H, params->kernel[0] + (size_t)desc->x_dim * pl.H, nullptr, ws + e.off_zt, stream);
+  if (rc != FRL_OK) return rc;
+  KArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xT = bufs->x; a.x0 = bufs->out; a.state_bias = ws + e.off_zt;
+  for (int l = 1; l < pl.L; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
+  a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
+  a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
+  a.ws_ln = desc->layer_norm ? ws + pl.off_ln : nullptr;
+  a.B = pl.B; a.particles = 1; a.A = pl.A; a.C = 0; a.T = 1; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
+  a.NE = 1; a.AO = pl.AO;
+  a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
+  a.mode = MODE_EVAL;
+  a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
+  a.wl_raw = params->kernel[pl.L];
+  return launch_f32_network(a, desc->act, desc->tile_policy, stream);
+}
+
+int frl_add_noise(int32_t kind, int64_t B, int32_t A, const float* x0, const float* e, const void* t, const float* alpha_hats,
+                  int32_t steps, float p0, float p1, float* xt, float* vel, void* hip_stream) {
+  if (kind < FRL_NOISE_DDPM || kind > FRL_NOISE_FLOW) { set_error("add_noise: kind %d invalid", kind); return FRL_EINVAL; }
+  if (B < 0 || A < 1) { set_error("add_noise: B %lld / A %d invalid", (long long)B, A); return FRL_EINVAL; }
+  if (B == 0) return FRL_OK;
+  if (x0 == nullptr || e == nullptr || t == nullptr || xt == nullptr) { set_error("add_noise: x0 / e / t / xt is NULL"); return FRL_EINVAL; }
+  if (kind == FRL_NOISE_DDPM && (alpha_hats == nullptr || steps < 1)) { set_error("add_noise: alpha_hats (steps + 1,) required"); return FRL_EINVAL; }
+  return launch_add_noise(kind, B, A, x0, e, t, alpha_hats, p0, p1, xt, vel, (hipStream_t)hip_stream);
+}
+
+int frl_ddpm_onestep_update(int32_t solver, int64_t B, int32_t A, int32_t num_samples, const float* xt, const float* eps_theta,
+                            const int32_t* t, const float* alphas, const float* alpha_hats, int32_t steps, int32_t clip, float x_min,
+                            float x_max, const float* noise, float* out, void* hip_stream) {
+  if (solver != FRL_SOLVER_DDPM && solver != FRL_SOLVER_DDIM) { set_error("onestep update: solver %d (ddpm / ddim, ddpm.py:16-18)", solver); return FRL_EINVAL; }
+  if (B < 0 || A < 1 || num_samples < 1 || steps < 1) { set_error("onestep update: bad sizes"); return FRL_EINVAL; }
+  if (B == 0) return FRL_OK;
+  if (xt == nullptr || eps_theta == nullptr || t == nullptr || alphas == nullptr || alpha_hats == nullptr || out == nullptr) { set_error("onestep update: NULL argument"); return FRL_EINVAL; }
+  if (solver == FRL_SOLVER_DDPM && noise == nullptr) { set_error("onestep update: the ddpm solver needs noise (B, num_samples, A)"); return FRL_EINVAL; }
+  return launch_onestep_update(solver, B, A, num_samples, xt, eps_theta, t, alphas, alpha_hats, clip, x_min, x_max, noise, out, (hipStream_t)hip_stream);
+}
+
+int frl_mse_loss(int64_t n, const float* pred, const float* target, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                 void* hip_stream) {
+  if (n < 1 || pred == nullptr || target == nullptr || loss == nullptr) { set_error("mse: bad arguments"); return FRL_EINVAL; }
+  if (workspace == nullptr || workspace_bytes < FRL_MSE_WORKSPACE_BYTES || ((uintptr_t)workspace & 7) != 0) { set_error("mse: workspace of FRL_MSE_WORKSPACE_BYTES required"); return FRL_EWORKSPACE; }
+  return launch_mse(n, pred, target, loss, grad, workspace, (hipStream_t)hip_stream);
+}
+
 int frl_selftest_mfma32(const float* A, const float* B, float* D, int K, void* hip_stream) {
   if (A == nullptr || B == nullptr || D == nullptr || K < 2 || (K & 1)) { set_error("selftest: bad arguments"); return FRL_EINVAL; }
   return launch_selftest_mfma32(A, B, D, K, (hipStream_t)hip_stream);

@@ -355,6 +355,15 @@ int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, c
 int launch_critic_select(const float* q_members, int E, long long n_states, int particles, int A, const float* actions,
                          const float* gumbel, float inv_temperature, float* q, int32_t* best_idx, float* best_action,
                          hipStream_t stream);
+int launch_random_uniform(const uint32_t* key, int impl, long long n, float lo, float hi, float* out, hipStream_t stream);
+int launch_random_randint(const uint32_t* key, int impl, long long n, int32_t minval, int32_t maxval, int32_t* out, hipStream_t stream);
+// csrc/net_eval.hip: per-sample-time evaluation rows and the forward-process pieces
+int launch_time_rows(const FrlDesc& d, const FrlParams& p, const float* t, const float* cond, int C, float* u, long long B, hipStream_t stream);
+int launch_add_noise(int kind, long long B, int A, const float* x0, const float* e, const void* t, const float* alpha_hats, float p0, float p1,
+                     float* xt, float* vel, hipStream_t stream);
+int launch_onestep_update(int solver, long long B, int A, int N, const float* xt, const float* eps, const int32_t* t, const float* alphas,
+                          const float* alpha_hats, int clip, float x_min, float x_max, const float* noise, float* out, hipStream_t stream);
+int launch_mse(long long n, const float* pred, const float* target, float* loss, float* grad, void* ws, hipStream_t stream);
 int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);
 
 }  // namespace frl

@@ -78,6 +78,38 @@ __global__ void frl_random_fill_kernel(const uint32_t* __restrict__ key, int imp
   }
 }
 
+// jax.random.uniform(key, shape, minval, maxval): mantissa-trick float in [0, 1) * (maxval - minval) + minval, floored at
+// minval (jax/_src/random.py _uniform) — the t draw of ContinuousDDPM.add_noise / CNF.linear_interpolation
+__global__ void frl_random_uniform_kernel(const uint32_t* __restrict__ key, int impl, unsigned long long n, float lo, float hi, float* __restrict__ out) {
+#pragma clang fp contract(off)      // separate multiply and add, as XLA:CPU evaluates floats * (maxval - minval) + minval
+  const uint32_t k0 = key[0], k1 = key[1];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t b = rng_bits(k0, k1, impl, n, i);
+    const float f = __uint_as_float((b >> 9) | 0x3F800000u) - 1.0f;
+    const float scaled = f * (hi - lo);
+    out[i] = fmaxf(lo, scaled + lo);
+  }
+}
+
+// jax.random.randint(key, shape, minval, maxval) for int32 (jax/_src/random.py _randint): k1, k2 = split(key); two uint32
+// draws (higher, lower); span = maxval - minval; multiplier = (2^16 mod span)^2 mod span;
+// offset = ((higher mod span) * multiplier + lower mod span) mod span in wrapping uint32 arithmetic — the t draw of DDPM.add_noise
+__global__ void frl_random_randint_kernel(const uint32_t* __restrict__ key, int impl, unsigned long long n, int32_t minval, int32_t maxval,
+                                          int32_t* __restrict__ out) {
+  uint32_t a0, a1, b0, b1;
+  split_word(key[0], key[1], impl, 2, 0, a0, a1);
+  split_word(key[0], key[1], impl, 2, 1, b0, b1);
+  uint32_t span = (uint32_t)(maxval - minval);
+  if (maxval <= minval) span = 1u;
+  uint32_t mult = 65536u % span;
+  mult = (mult * mult) % span;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t hi = rng_bits(a0, a1, impl, n, i), lo = rng_bits(b0, b1, impl, n, i);
+    const uint32_t off = ((hi % span) * mult + (lo % span)) % span;
+    out[i] = minval + (int32_t)off;
+  }
+}
+
 static int check_impl(int impl) {
   if (impl == FRL_RNG_THREEFRY_PARTITIONABLE || impl == FRL_RNG_THREEFRY_LEGACY) return FRL_OK;
   set_error("rng impl %d: FRL_RNG_THREEFRY_PARTITIONABLE or FRL_RNG_THREEFRY_LEGACY expected", impl);
@@ -107,6 +139,32 @@ int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, in
   else hipLaunchKernelGGL(frl_random_fill_kernel<0>, dim3(grid), dim3(256), 0, stream, key, impl, (unsigned long long)n, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("random fill launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+int launch_random_uniform(const uint32_t* key, int impl, long long n, float lo, float hi, float* out, hipStream_t stream) {
+  int rc = check_impl(impl);
+  if (rc != FRL_OK) return rc;
+  if (key == nullptr || (out == nullptr && n > 0) || n < 0) { set_error("random uniform: bad arguments"); return FRL_EINVAL; }
+  if (impl == FRL_RNG_THREEFRY_LEGACY && n > 0xFFFFFFFFll) { set_error("legacy threefry layout: at most 2^32 - 1 elements per draw"); return FRL_EUNSUPPORTED; }
+  if (n == 0) return FRL_OK;
+  const long long want = (n + 255) / 256, cap = 16ll * device_cus();
+  hipLaunchKernelGGL(frl_random_uniform_kernel, dim3((int)(want < cap ? want : cap)), dim3(256), 0, stream, key, impl, (unsigned long long)n, lo, hi, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("random uniform launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
+int launch_random_randint(const uint32_t* key, int impl, long long n, int32_t minval, int32_t maxval, int32_t* out, hipStream_t stream) {
+  int rc = check_impl(impl);
+  if (rc != FRL_OK) return rc;
+  if (key == nullptr || (out == nullptr && n > 0) || n < 0) { set_error("random randint: bad arguments"); return FRL_EINVAL; }
+  if (impl == FRL_RNG_THREEFRY_LEGACY && n > 0xFFFFFFFFll) { set_error("legacy threefry layout: at most 2^32 - 1 elements per draw"); return FRL_EUNSUPPORTED; }
+  if (n == 0) return FRL_OK;
+  const long long want = (n + 255) / 256, cap = 16ll * device_cus();
+  hipLaunchKernelGGL(frl_random_randint_kernel, dim3((int)(want < cap ? want : cap)), dim3(256), 0, stream, key, impl, (unsigned long long)n, minval, maxval, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("random randint launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
 }
 

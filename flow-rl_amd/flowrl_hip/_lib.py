@@ -77,6 +77,14 @@ class FrlSelectBufs(C.Structure):
                 ("best_idx", _fp), ("best_action", _fp)]
 
 
+class FrlEvalBufs(C.Structure):
+    _fields_ = [("x", _fp), ("cond", _fp), ("t", _fp), ("out", _fp)]
+
+
+FRL_NOISE_DDPM, FRL_NOISE_CDDPM_LINEAR, FRL_NOISE_CDDPM_COSINE, FRL_NOISE_FLOW = 0, 1, 2, 3
+FRL_MSE_WORKSPACE_BYTES = 2048
+
+
 class FlowRLHipError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libflowrl_hip error {code}: {msg}")
@@ -118,6 +126,15 @@ EXPORTS = {
     "frl_random_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "frl_random_bits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "frl_random_gumbel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "frl_random_uniform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "frl_random_randint": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "frl_net_eval_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
+    "frl_net_eval": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlEvalBufs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_add_noise": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
+                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frl_ddpm_onestep_update": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frl_mse_loss": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_selftest_mfma32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

@@ -1,0 +1,120 @@
+"""Host side of the training-side half of the flow models: the per-sample-time network
+evaluation and the forward-process pieces, marshalled onto the C ABI (include/flowrl_hip.h: frl_net_eval, frl_add_noise,
+frl_ddpm_onestep_update, frl_mse_loss, frl_random_uniform / randint).  As everywhere in this package PyTorch only owns
+memory and streams; there is no eager / CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from . import random as _random
+from ._sampler import _f32c, _split_condition, _workspace, build_desc, build_params, check_param_shapes
+
+
+def net_eval(network, params: Dict, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, *,
+             particles: Optional[int] = None, tile_policy: str = "auto") -> torch.Tensor:
+    """``self(x, t, condition)`` of a DDPMBackbone / FlowBackbone model with a per-sample time input
+    (ddpm.py:249-254, 286-293; continuous_ddpm.py:234-241; cnf.py:155-162).  ``t``: (..., 1) or (...) matching x's leading
+    dims — integer steps (DDPM) are promoted to float32 exactly as ``t_proto * t`` is by the embedding."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError("flowrl_hip runs on the GPU only; there is no CPU fallback")
+    device = x.device
+    A = x.shape[-1]
+    lead = tuple(x.shape[:-1])
+    n_states, parts, cond2d = _split_condition(x, condition, particles)
+    cond_dim = 0 if cond2d is None else cond2d.shape[-1]
+    check_param_shapes(network, params, A, cond_dim)
+    keep: list = []
+    desc = build_desc(network, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=1, n_states=n_states, particles=parts,
+                      x_dim=A, cond_dim=cond_dim, clip_sampler=False, x_min=None, x_max=None, want_history=False,
+                      tile_policy=tile_policy)
+    fparams = build_params(network, params, device, keep)
+    B = n_states * parts
+    if t.numel() != B:
+        raise ValueError(f"t has {t.numel()} elements, expected one per sample ({B})")
+    tf = t.reshape(B).to(torch.float32)
+    tf = _f32c(tf, device, "t")
+    xin = _f32c(x.reshape(B, A), device, "x")
+    out = torch.empty((B, A), dtype=torch.float32, device=device)
+    bufs = _lib.FrlEvalBufs()
+    bufs.x, bufs.t, bufs.out = xin.data_ptr(), tf.data_ptr(), out.data_ptr()
+    if cond2d is not None:
+        cond2d = _f32c(cond2d, device, "condition")
+        bufs.cond = cond2d.data_ptr()
+    need = lib.frl_net_eval_workspace_bytes(C.byref(desc))
+    stream = torch.cuda.current_stream(device).cuda_stream
+    if need == 0:
+        _lib.check(lib.frl_net_eval(C.byref(desc), C.byref(fparams), C.byref(bufs), None, 0, stream))
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "this configuration has no evaluation kernel")
+    ws = _workspace(need, device, stream)
+    with torch.cuda.device(device):
+        rc = lib.frl_net_eval(C.byref(desc), C.byref(fparams), C.byref(bufs), ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc)
+    return out.reshape(*lead, A)
+
+
+def add_noise(kind: int, x0: torch.Tensor, e: torch.Tensor, t: torch.Tensor, *, alpha_hats: Optional[torch.Tensor] = None,
+              steps: int = 0, p0: float = 0.0, p1: float = 0.0, want_vel: bool = False):
+    """frl_add_noise: xt (and vel for FRL_NOISE_FLOW) from (x0, e, t); t (..., 1) int32 (DDPM) or float32."""
+    lib = _lib.load()
+    device = x0.device
+    A = x0.shape[-1]
+    B = x0.numel() // A
+    x0c, ec = _f32c(x0.reshape(B, A), device, "x0"), _f32c(e.reshape(B, A), device, "eps / x1")
+    want_dtype = torch.int32 if kind == _lib.FRL_NOISE_DDPM else torch.float32
+    if t.dtype != want_dtype or t.numel() != B:
+        raise TypeError(f"t: {B} values of {want_dtype} expected")
+    tc = t.reshape(B).contiguous()
+    xt = torch.empty_like(x0c)
+    vel = torch.empty_like(x0c) if want_vel else None
+    ah = None if alpha_hats is None else _f32c(alpha_hats, device, "alpha_hats")
+    with torch.cuda.device(device):
+        _lib.check(lib.frl_add_noise(kind, B, A, x0c.data_ptr(), ec.data_ptr(), tc.data_ptr(), None if ah is None else ah.data_ptr(),
+                                     int(steps), float(p0), float(p1), xt.data_ptr(), None if vel is None else vel.data_ptr(),
+                                     torch.cuda.current_stream(device).cuda_stream))
+    xt = xt.reshape(x0.shape)
+    return (xt, vel.reshape(x0.shape)) if want_vel else xt
+
+
+def onestep_update(solver: int, xt: torch.Tensor, eps_theta: torch.Tensor, t: torch.Tensor, alphas: torch.Tensor, alpha_hats: torch.Tensor,
+                   steps: int, num_samples: int, clip: bool, x_min, x_max, noise: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    device = xt.device
+    B, A = xt.shape
+    out = torch.empty((B, num_samples, A), dtype=torch.float32, device=device)
+    xc, ec = _f32c(xt, device, "xt"), _f32c(eps_theta, device, "eps_theta")
+    tc = t.reshape(B).to(torch.int32).contiguous()
+    nz = None if noise is None else _f32c(noise.reshape(B, num_samples, A), device, "noise")
+    with torch.cuda.device(device):
+        _lib.check(lib.frl_ddpm_onestep_update(solver, B, A, int(num_samples), xc.data_ptr(), ec.data_ptr(), tc.data_ptr(),
+                                               alphas.data_ptr(), alpha_hats.data_ptr(), int(steps), 1 if clip else 0,
+                                               float(x_min) if x_min is not None else float("-inf"),
+                                               float(x_max) if x_max is not None else float("inf"),
+                                               None if nz is None else nz.data_ptr(), out.data_ptr(),
+                                               torch.cuda.current_stream(device).cuda_stream))
+    return out
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = False):
+    """((pred - target) ** 2).mean() (ddpm.py:294, cnf.py:163) as a device scalar; with ``want_grad`` also dloss/dpred."""
+    lib = _lib.load()
+    device = pred.device
+    p, q = _f32c(pred.reshape(-1), device, "pred"), _f32c(target.reshape(-1), device, "target")
+    if p.numel() != q.numel() or p.numel() == 0:
+        raise ValueError("mse_loss: pred / target of the same non-zero size expected")
+    loss = torch.empty((), dtype=torch.float32, device=device)
+    grad = torch.empty_like(p) if want_grad else None
+    ws = torch.empty(_lib.FRL_MSE_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.frl_mse_loss(p.numel(), p.data_ptr(), q.data_ptr(), loss.data_ptr(), None if grad is None else grad.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream(device).cuda_stream))
+    return (loss, grad.reshape(pred.shape)) if want_grad else loss
+
+
+def split3(rng, impl=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    k = _random.split(rng, 3, impl)
+    return k[0].contiguous(), k[1].contiguous(), k[2].contiguous()

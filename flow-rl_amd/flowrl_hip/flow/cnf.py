@@ -7,7 +7,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .. import _lib
+from .. import _lib, _train
 from .. import random as _random
 from .._sampler import run_sampler, run_sampler_train, run_sampler_vjp
 from ..module import FlowBackbone, init_params
@@ -64,6 +64,25 @@ class ContinuousNormalizingFlow:
             rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch)
         return (out[2] if key is not None else rng), out[0], out[1]
 
+    # ---- training-side half ---------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+                 params: Optional[Dict] = None, *, particles: Optional[int] = None) -> torch.Tensor:
+        """``self(xt, t, condition)`` with a per-sample time in [0, 1] (frl_net_eval)."""
+        p = params if (training and params is not None) else self.params
+        return _train.net_eval(self.network, p, x, t, condition, particles=particles)
+
+    def step2t(self, step):
+        """cnf.py:80-83."""
+        return step / self.steps
+
+    def linear_interpolation(self, rng, x0: torch.Tensor, x1: torch.Tensor, *, rng_impl: Optional[str] = None):
+        """ContinuousNormalizingFlow.linear_interpolation (cnf.py:85-90): rng, t_rng = split(rng, 2);
+        t = uniform(t_rng, (..., 1)); xt = (1 - t) x0 + t x1; vel = x1 - x0.  Returns (rng, xt, t, vel)."""
+        keys = _random.split(rng, 2, rng_impl)
+        t = _random.uniform(keys[1].contiguous(), (*x1.shape[:-1], 1), 0.0, 1.0, rng_impl)
+        xt, vel = _train.add_noise(_lib.FRL_NOISE_FLOW, x0, x1, t, want_vel=True)
+        return keys[0].contiguous(), xt, t, vel
+
     def sample_vjp(self, xt_hist: torch.Tensor, g_x1: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gx0: bool = True,
                    compute_dtype: str = "f32", ctx=None):
@@ -76,3 +95,13 @@ class ContinuousNormalizingFlow:
             self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xt_hist=xt_hist,
             condition=condition, g_x0=g_x1, sched={}, tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
             x_max=self.x_max, particles=particles, want_gxT=want_gx0, compute_dtype=compute_dtype, ctx=ctx)
+
+
+def flow_matching_loss(rng, model: ContinuousNormalizingFlow, x0: torch.Tensor, x1: torch.Tensor,
+                       condition: Optional[torch.Tensor] = None, params: Optional[Dict] = None, *, rng_impl: Optional[str] = None):
+    """The loss of jit_update_flow_matching (cnf.py:145-170): rng, xt, t, vel = model.linear_interpolation(rng, x0, x1);
+    vel_pred = model.apply(params, xt, t, condition); loss = ((vel_pred - vel) ** 2).mean().  Returns (rng, loss, aux)."""
+    rng, xt, t, vel = model.linear_interpolation(rng, x0, x1, rng_impl=rng_impl)
+    vel_pred = model(xt, t, condition, True, params if params is not None else model.params)
+    loss, g = _train.mse_loss(vel_pred, vel, want_grad=True)
+    return rng, loss, {"xt": xt, "t": t, "vel": vel, "vel_pred": vel_pred, "g_vel_pred": g}

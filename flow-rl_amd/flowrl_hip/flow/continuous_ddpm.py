@@ -8,7 +8,7 @@ from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
-from .. import _lib, schedules
+from .. import _lib, _train, schedules
 from .. import random as _random
 from .._sampler import run_sampler, run_sampler_train, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
@@ -110,6 +110,34 @@ class ContinuousDDPM:
             particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch)
         return (out[2] if key is not None else rng), out[0], out[1]
 
+    # ---- training-side half ---------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+                 params: Optional[Dict] = None, *, particles: Optional[int] = None) -> torch.Tensor:
+        """``self(xt, t, condition)`` with a per-sample continuous time (frl_net_eval)."""
+        p = params if (training and params is not None) else self.params
+        return _train.net_eval(self.network, p, x, t, condition, particles=particles)
+
+    def _noise_kind(self):
+        fn = self.noise_schedule_func
+        name = getattr(getattr(fn, "func", fn), "__name__", "")
+        kw = dict(getattr(fn, "keywords", {}) or {})
+        if name == "linear_noise_schedule":
+            return _lib.FRL_NOISE_CDDPM_LINEAR, float(kw.get("beta0", 0.1)), float(kw.get("beta1", 20.0))
+        if name == "cosine_noise_schedule":
+            return _lib.FRL_NOISE_CDDPM_COSINE, float(kw.get("s", 0.008)), 0.0
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, f"noise_schedule_func {name!r}: linear / cosine have kernels")
+
+    def add_noise(self, rng, x0: torch.Tensor, *, rng_impl: Optional[str] = None):
+        """ContinuousDDPM.add_noise (continuous_ddpm.py:107-115): t = uniform(t_rng, (..., 1), t_diffusion[0], t_diffusion[1]);
+        eps = normal(noise_rng, x0.shape); alpha, sigma = noise_schedule_func(t); xt = alpha x0 + sigma eps.
+        Returns (rng, xt, t, eps)."""
+        keys = _random.split(rng, 3, rng_impl)
+        t = _random.uniform(keys[1].contiguous(), (*x0.shape[:-1], 1), self.t_diffusion[0], self.t_diffusion[1], rng_impl)
+        eps = _random.normal(keys[2].contiguous(), tuple(x0.shape), rng_impl)
+        kind, p0, p1 = self._noise_kind()
+        xt = _train.add_noise(kind, x0, eps, t, p0=p0, p1=p1)
+        return keys[0].contiguous(), xt, t, eps
+
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                    params: Optional[Dict] = None, *, particles: Optional[int] = None, want_gxT: bool = True,
@@ -133,3 +161,12 @@ class ContinuousDDPM:
             condition=condition, g_x0=g_x0, sched={"ts": to(ts), "alpha_hats": to(ah), "alphas": to(al), "betas": to(be)},
             tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, particles=particles,
             want_gxT=want_gxT, compute_dtype=compute_dtype, ctx=ctx)
+
+
+def continuous_ddpm_loss(rng, model: ContinuousDDPM, x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                         params: Optional[Dict] = None, *, rng_impl: Optional[str] = None):
+    """The loss of jit_update_continuous_ddpm (continuous_ddpm.py:226-245).  Returns (rng, loss, aux) as ddpm_loss does."""
+    rng, xt, t, eps = model.add_noise(rng, x0, rng_impl=rng_impl)
+    eps_pred = model(xt, t, condition, True, params if params is not None else model.params)
+    loss, g = _train.mse_loss(eps_pred, eps, want_grad=True)
+    return rng, loss, {"xt": xt, "t": t, "eps": eps, "eps_pred": eps_pred, "g_eps_pred": g}

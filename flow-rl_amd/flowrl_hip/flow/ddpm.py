@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from .. import _lib, schedules
+from .. import _lib, _train, schedules
 from .. import random as _random
 from .._sampler import run_sampler, run_sampler_train, run_sampler_vjp
 from ..module import DDPMBackbone, init_params
@@ -103,6 +103,52 @@ class DDPM:
             particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch)
         return (out[2] if key is not None else rng), out[0], out[1]
 
+    # ---- training-side half ---------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+                 params: Optional[Dict] = None, *, particles: Optional[int] = None) -> torch.Tensor:
+        """``self(xt, t, condition)`` (module/model.py:62-73 -> DDPMBackbone, ddpm.py:83-95) with a per-sample time input:
+        one fused MFMA evaluation per sample (frl_net_eval).  ``t``: integer steps, (..., 1) or (...)."""
+        p = params if (training and params is not None) else self.params
+        return _train.net_eval(self.network, p, x, t, condition, particles=particles)
+
+    def add_noise(self, rng, x0: torch.Tensor, *, rng_impl: Optional[str] = None):
+        """DDPM.add_noise (ddpm.py:164-171): rng, t_rng, noise_rng = split(rng, 3); t = randint(t_rng, (..., 1), 1, steps + 1);
+        eps = normal(noise_rng, x0.shape); xt = sqrt(alpha_hats[t]) x0 + sqrt(1 - alpha_hats[t]) eps.  ``rng``: a threefry key
+        (flowrl_hip.random).  Returns (rng, xt, t, eps) — t int32 (..., 1)."""
+        keys = _random.split(rng, 3, rng_impl)
+        t = _random.randint(keys[1].contiguous(), (*x0.shape[:-1], 1), 1, self.steps + 1, rng_impl)
+        eps = _random.normal(keys[2].contiguous(), tuple(x0.shape), rng_impl)
+        xt = _train.add_noise(_lib.FRL_NOISE_DDPM, x0, eps, t, alpha_hats=self.alpha_hats, steps=self.steps)
+        return keys[0].contiguous(), xt, t, eps
+
+    def onestep_sample(self, rng, xt_or_x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
+                       num_samples: Optional[int] = None, solver: str = "ddpm", sample_xt: bool = True,
+                       t: Optional[torch.Tensor] = None, params: Optional[Dict] = None, *, rng_impl: Optional[str] = None):
+        """DDPM.onestep_sample (ddpm.py:223-276), same positional signature and return tuple
+        (rng, repeated_xt_1, xt, repeated_t_1, t, eps_theta): optionally noise x0 to a random step, evaluate the network
+        once per sample at ITS step, take one reverse step and repeat it num_samples times with fresh noise."""
+        if solver not in SUPPORTED_SOLVERS:
+            raise NotImplementedError(f"Unsupported solver {solver} for {type(self)}")
+        if xt_or_x0.dim() != 2:
+            raise ValueError("onestep_sample: (B, A) input expected (ddpm.py:235: B = xt_or_x0.shape[0])")
+        B = xt_or_x0.shape[0]
+        N = int(num_samples) if num_samples is not None else 1
+        keys = _random.split(rng, 4, rng_impl)                     # rng, sample_rng, noise_rng, dropout_rng (ddpm.py:236)
+        if sample_xt:
+            _, xt, t, _eps_sample = self.add_noise(keys[1].contiguous(), xt_or_x0, rng_impl=rng_impl)
+        else:
+            if t is None:
+                raise ValueError("onestep_sample(sample_xt=False) needs t")
+            xt = xt_or_x0
+            t = t.reshape(B, 1).to(torch.int32)
+        repeated_t = t.repeat_interleave(N, dim=0).reshape(B, N, -1)        # t.repeat(num_samples, axis=0).reshape(...), :243
+        repeated_t_1 = repeated_t - 1
+        eps_theta = self(xt, t, condition, training, params)
+        noise = _random.normal(keys[2].contiguous(), (B, N, xt.shape[-1]), rng_impl) if solver == "ddpm" else None
+        rep = _train.onestep_update(_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM, xt, eps_theta, t,
+                                    self.alphas, self.alpha_hats, self.steps, N, bool(self.clip_sampler), self.x_min, self.x_max, noise)
+        return keys[0].contiguous(), rep, xt, repeated_t_1, t, eps_theta
+
     def sample_vjp(self, xt_hist: torch.Tensor, g_x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
                    solver: str = "ddpm", params: Optional[Dict] = None, *, particles: Optional[int] = None,
                    want_gxT: bool = True, compute_dtype: str = "f32", ctx=None) -> Tuple[Dict, Optional[torch.Tensor]]:
@@ -123,3 +169,14 @@ class DDPM:
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             tvals=tvals, clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
             particles=particles, want_gxT=want_gxT, compute_dtype=compute_dtype, ctx=ctx)
+
+
+def ddpm_loss(rng, model: DDPM, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, params: Optional[Dict] = None, *,
+              rng_impl: Optional[str] = None):
+    """The loss of jit_update_ddpm (ddpm.py:280-304): rng, xt, t, eps = model.add_noise(rng, x0);
+    eps_pred = model.apply(params, xt, t, condition); loss = ((eps_pred - eps) ** 2).mean().  Returns (rng, loss, aux) with
+    aux = {xt, t, eps, eps_pred, g_eps_pred = dloss / deps_pred}; the optimizer step (optax, model.py:78-86) stays with the caller."""
+    rng, xt, t, eps = model.add_noise(rng, x0, rng_impl=rng_impl)
+    eps_pred = model(xt, t, condition, True, params if params is not None else model.params)
+    loss, g = _train.mse_loss(eps_pred, eps, want_grad=True)
+    return rng, loss, {"xt": xt, "t": t, "eps": eps, "eps_pred": eps_pred, "g_eps_pred": g}

@@ -83,3 +83,26 @@ def bits(key: torch.Tensor, shape, impl: str = None) -> torch.Tensor:
 def gumbel(key: torch.Tensor, shape, impl: str = None) -> torch.Tensor:
     """jax.random.gumbel(key, shape) (float32): the noise jax.random.categorical adds to its logits (dql.py:159-160)."""
     return _fill("frl_random_gumbel", key, shape, torch.float32, impl)
+
+
+def uniform(key: torch.Tensor, shape, minval: float = 0.0, maxval: float = 1.0, impl: str = None) -> torch.Tensor:
+    """jax.random.uniform(key, shape, minval=, maxval=) (float32): the t draw of ContinuousDDPM.add_noise
+    (continuous_ddpm.py:110) and CNF.linear_interpolation (cnf.py:87)."""
+    lib = _lib.load()
+    key = as_key(key, key.device if isinstance(key, torch.Tensor) and key.is_cuda else "cuda")
+    shape = tuple(int(v) for v in (shape if isinstance(shape, Sequence) else (shape,)))
+    out = torch.empty(shape, dtype=torch.float32, device=key.device)
+    with torch.cuda.device(key.device):
+        _lib.check(lib.frl_random_uniform(key.data_ptr(), impl_id(impl), math.prod(shape), float(minval), float(maxval), out.data_ptr(), _stream(key.device)))
+    return out
+
+
+def randint(key: torch.Tensor, shape, minval: int, maxval: int, impl: str = None) -> torch.Tensor:
+    """jax.random.randint(key, shape, minval, maxval) (int32): the t draw of DDPM.add_noise (ddpm.py:167)."""
+    lib = _lib.load()
+    key = as_key(key, key.device if isinstance(key, torch.Tensor) and key.is_cuda else "cuda")
+    shape = tuple(int(v) for v in (shape if isinstance(shape, Sequence) else (shape,)))
+    out = torch.empty(shape, dtype=torch.int32, device=key.device)
+    with torch.cuda.device(key.device):
+        _lib.check(lib.frl_random_randint(key.data_ptr(), impl_id(impl), math.prod(shape), int(minval), int(maxval), out.data_ptr(), _stream(key.device)))
+    return out

@@ -324,6 +324,51 @@ int frl_random_normal(const uint32_t* key, int32_t impl, int64_t n, float* out, 
 int frl_random_bits(const uint32_t* key, int32_t impl, int64_t n, uint32_t* out, void* hip_stream);
 int frl_random_gumbel(const uint32_t* key, int32_t impl, int64_t n, float* out, void* hip_stream);
 
+int frl_random_uniform(const uint32_t* key, int32_t impl, int64_t n, float minval, float maxval, float* out, void* hip_stream);
+int frl_random_randint(const uint32_t* key, int32_t impl, int64_t n, int32_t minval, int32_t maxval, int32_t* out, void* hip_stream);
+
+/* ---- the training-side half of the flow models --------------------------------------------------
+ * frl_net_eval: ONE network evaluation per sample with a PER-SAMPLE time input — `self(xt, t, condition)` as
+ * onestep_sample (ddpm.py:249-254) and the epsilon-MSE / flow-matching losses call it (ddpm.py:286-293,
+ * continuous_ddpm.py:234-241, cnf.py:155-162).  desc describes the network (x_dim, cond_dim / cond_embed, time_embed,
+ * hidden, act, layer_norm, n_states x particles samples; kind / solver / steps / clip are ignored); f32. */
+typedef struct FrlEvalBufs {
+  const float* x;    /* (B, A) network input x (xt)                                                         */
+  const float* cond; /* (n_states, C) un-repeated condition rows ((n_states, cond_in_dim) with cond_embed)  */
+  const float* t;    /* (B,) time input per sample AS THE NETWORK SEES IT: float(t) for DDPM's integer steps */
+  float* out;        /* (B, A) eps_theta / velocity                                                          */
+} FrlEvalBufs;
+size_t frl_net_eval_workspace_bytes(const FrlDesc* desc);
+int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* workspace, size_t workspace_bytes,
+                 void* hip_stream);
+
+/* Forward process, elementwise over (B, A):
+ *   FRL_NOISE_DDPM          xt = sqrt(alpha_hats[t]) x0 + sqrt(1 - alpha_hats[t]) eps, t (B,) int32   ddpm.py:164-171
+ *   FRL_NOISE_CDDPM_LINEAR  alpha, sigma = linear_noise_schedule(t, beta0 = p0, beta1 = p1)            continuous_ddpm.py:19-24,107-115
+ *   FRL_NOISE_CDDPM_COSINE  alpha, sigma = cosine_noise_schedule(t, s = p0); xt = alpha x0 + sigma eps  continuous_ddpm.py:26-31
+ *   FRL_NOISE_FLOW          xt = (1 - t) x0 + t x1, vel = x1 - x0  (e = x1; vel may be NULL)            cnf.py:85-90
+ * t is (B,) int32 for FRL_NOISE_DDPM, (B,) float32 otherwise. */
+#define FRL_NOISE_DDPM 0
+#define FRL_NOISE_CDDPM_LINEAR 1
+#define FRL_NOISE_CDDPM_COSINE 2
+#define FRL_NOISE_FLOW 3
+int frl_add_noise(int32_t kind, int64_t B, int32_t A, const float* x0, const float* e, const void* t, const float* alpha_hats,
+                  int32_t steps, float p0, float p1, float* xt, float* vel, void* hip_stream);
+
+/* DDPM.onestep_sample's update (ddpm.py:256-274) for per-sample integer t in [1, steps]: xt_1 from (xt, eps_theta), each
+ * row repeated num_samples times; solver ddpm adds (t > 1) sqrt(1 - alphas[t]) noise (noise (B, num_samples, A)), ddim clips.
+ * out is (B, num_samples, A). */
+int frl_ddpm_onestep_update(int32_t solver, int64_t B, int32_t A, int32_t num_samples, const float* xt, const float* eps_theta,
+                            const int32_t* t, const float* alphas, const float* alpha_hats, int32_t steps, int32_t clip, float x_min,
+                            float x_max, const float* noise, float* out, void* hip_stream);
+
+/* loss = ((pred - target) ** 2).mean() over n elements (ddpm.py:294, continuous_ddpm.py:242, cnf.py:163) into the device
+ * scalar `loss`; grad (n,) or NULL receives dloss/dpred = 2 (pred - target) / n.  Deterministic (fixed-order sums);
+ * workspace: FRL_MSE_WORKSPACE_BYTES. */
+#define FRL_MSE_WORKSPACE_BYTES 2048
+int frl_mse_loss(int64_t n, const float* pred, const float* target, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                 void* hip_stream);
+
 int frl_abi_version(void);
 
 /* Hardware self-test of the MFMA operand / accumulator lane maps the kernel relies on:

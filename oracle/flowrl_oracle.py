@@ -303,6 +303,64 @@ def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
 
 
 # --------------------------------------------------------------------------- #
+# training-side half: forward process, one-step sample, losses
+# --------------------------------------------------------------------------- #
+
+
+def ddpm_add_noise(tables, x0, t, eps):
+    """DDPM.add_noise given its draws (ddpm.py:170): t int (..., 1) in [1, steps]."""
+    _, _, ah, _ = tables
+    a = ah[t]
+    return np.sqrt(a) * x0 + np.sqrt(1 - a) * eps
+
+
+def continuous_add_noise(noise_schedule: str, x0, t, eps):
+    """ContinuousDDPM.add_noise given its draws (continuous_ddpm.py:113-114)."""
+    alpha, sigma = (cosine_noise_schedule if noise_schedule == "cosine" else linear_noise_schedule)(t)
+    return alpha * x0 + sigma * eps
+
+
+def linear_interpolation(x0, x1, t):
+    """ContinuousNormalizingFlow.linear_interpolation given its draw (cnf.py:88-89): (xt, vel)."""
+    return (1 - t) * x0 + t * x1, x1 - x0
+
+
+def ddpm_onestep_update(tables, xt, eps_theta, t, num_samples, noise, *, solver="ddpm", clip_sampler=False, x_min=None, x_max=None):
+    """The update half of DDPM.onestep_sample (ddpm.py:242-274) given the network output and the noise draw:
+    returns (repeated_xt_1 (B, N, A), repeated_t_1 (B, N, 1))."""
+    _, al, ah, _ = tables
+    B = xt.shape[0]
+    t_1 = t - 1
+    repeated_t = t.repeat(num_samples, axis=0).reshape(B, num_samples, -1)
+    repeated_t_1 = t_1.repeat(num_samples, axis=0).reshape(B, num_samples, -1)
+    if solver == "ddpm":
+        x0_hat = 1 / np.sqrt(ah[t]) * (xt - np.sqrt(1 - ah[t]) * eps_theta)
+        if clip_sampler:
+            x0_hat = _clip(x0_hat, x_min, x_max)
+        xt_1 = 1 / (1 - ah[t]) * (np.sqrt(ah[t - 1]) * (1 - al[t]) * x0_hat + np.sqrt(al[t]) * (1 - ah[t - 1]) * xt)
+        rep = xt_1.repeat(num_samples, axis=0).reshape(B, num_samples, -1)
+        std_t = np.sqrt(1 - al[repeated_t])
+        rep = rep + (repeated_t > 1) * std_t * noise
+    elif solver == "ddim":
+        a1 = 1 / np.sqrt(al[t])
+        a2 = np.sqrt(1 - ah[t])
+        a3 = np.sqrt(1 - ah[t - 1])
+        xt_1 = a1 * (xt - a2 * eps_theta) + a3 * eps_theta
+        rep = xt_1.repeat(num_samples, axis=0).reshape(B, num_samples, -1)
+        if clip_sampler:
+            rep = _clip(rep, x_min, x_max)
+    else:
+        raise NotImplementedError(solver)
+    return rep, repeated_t_1
+
+
+def mse(pred, target):
+    """((pred - target) ** 2).mean() and its gradient w.r.t. pred (ddpm.py:294, continuous_ddpm.py:242, cnf.py:163)."""
+    d = pred - target
+    return (d ** 2).mean(), 2.0 * d / d.size
+
+
+# --------------------------------------------------------------------------- #
 # samplers
 # --------------------------------------------------------------------------- #
 

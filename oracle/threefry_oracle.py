@@ -119,6 +119,32 @@ def gumbel(key, shape, impl="partitionable"):
     return (-np.log(-np.log(u))).astype(np.float32)
 
 
+def uniform(key, shape, minval=0.0, maxval=1.0, impl="partitionable"):
+    """jax.random.uniform(key, shape, float32, minval, maxval) (jax/_src/random.py::_uniform): the mantissa trick on
+    random_bits, then * (maxval - minval) + minval, floored at minval.  PARITY UNPINNED above the bits (no published
+    vector quoted); call sites continuous_ddpm.py:110, cnf.py:87."""
+    return uniform_from_bits(random_bits(key, shape, impl), minval, maxval)
+
+
+def randint(key, shape, minval, maxval, impl="partitionable"):
+    """jax.random.randint(key, shape, minval, maxval) for int32 (jax/_src/random.py::_randint, jax 0.5.3):
+        k1, k2 = split(key); higher, lower = random_bits(k1), random_bits(k2)            (uint32)
+        span = uint32(maxval - minval) (1 when maxval <= minval)
+        multiplier = ((2**16 mod span) ** 2) mod span                                    (= 2**32 mod span)
+        offset = ((higher mod span) * multiplier + (lower mod span)) mod span            (wrapping uint32 arithmetic)
+        result = minval + int32(offset)
+    PARITY UNPINNED above the bits (restated from the published source, no vector quoted); call site ddpm.py:167."""
+    k1, k2 = split(key, 2, impl)
+    hi = random_bits(k1, shape, impl).astype(np.uint32)
+    lo = random_bits(k2, shape, impl).astype(np.uint32)
+    span = np.uint32(1) if maxval <= minval else np.uint32(maxval - minval)
+    mult = np.uint32(65536) % span
+    mult = np.uint32((np.uint64(mult) * np.uint64(mult)) & _M32) % span          # the product wraps in uint32 (span < 2**16 never does)
+    with np.errstate(over="ignore"):
+        off = ((hi % span) * mult + (lo % span)).astype(np.uint32) % span
+    return (np.int32(minval) + off.astype(np.int32)).astype(np.int32)
+
+
 def sampler_key_chain(kind, solver, steps, key, impl="partitionable"):
     """The split sequence inside the reference's scans.  Returns (noise_keys (n_steps, 2) uint32 — the key_ of every
     loop iteration, zeros where the solver draws none — and the rng the sampler returns)."""

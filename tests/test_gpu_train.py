@@ -1,0 +1,179 @@
+"""GPU parity of the training-side half of the flow models against the oracles:
+per-sample-time network evaluation (frl_net_eval), jax.random uniform / randint, add_noise / linear_interpolation,
+DDPM.onestep_sample, and the epsilon-MSE / flow-matching losses.  PARITY UNPINNED by the reference (no tests / fixtures).
+
+Bars: network outputs |hip - oracle64| <= 1e-5 max(|oracle64|, 1) (the sampler's first-evaluation bar); integer draws
+bit-exact; uniform bit-exact (the same float32 expression); elementwise float32 pieces <= 2e-6."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import flowrl_oracle as orc
+import helpers as H
+import threefry_oracle as tf
+
+pytestmark = pytest.mark.gpu
+
+
+def _t_for(case, rng, B):
+    if case.kind == "ddpm":
+        return rng.integers(1, case.T + 1, size=(B, 1)).astype(np.int32)
+    if case.kind == "cddpm":
+        return rng.uniform(1e-3, 0.9946, size=(B, 1)).astype(np.float32)
+    return rng.uniform(0.0, 1.0, size=(B, 1)).astype(np.float32)
+
+
+EVAL_CASES = [
+    H.Case("eval-dql", "ddpm", A=3, S=11, T=5, B=300),
+    H.Case("eval-toy-nocond", "ddpm", A=2, S=0, T=20, B=33, hidden=(256,), act="relu", seed=1),
+    H.Case("eval-cddpm-fourier", "cddpm", A=6, S=17, T=20, B=70, temb="learnable_fourier", schedule="cosine", act="silu", seed=2),
+    H.Case("eval-fql-512-raw-t", "cnf", A=8, S=39, T=10, B=100, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None, clip=False, seed=3),
+    H.Case("eval-dacer-embed-particles", "cddpm", A=17, S=376, T=20, B=6 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
+           cond_embed=True, seed=4),
+    H.Case("eval-layer-norm", "ddpm", A=3, S=11, T=5, B=64, ln=True, seed=5),
+    H.Case("eval-large", "ddpm", A=3, S=11, T=5, B=20000, seed=6),
+]
+
+
+@pytest.mark.parametrize("case", EVAL_CASES, ids=lambda c: c.name)
+def test_net_eval_per_sample_time(case):
+    import torch
+    params, xT, cond, _ = H.make_inputs(case)
+    rng = np.random.default_rng(50 + case.seed)
+    t = _t_for(case, rng, case.B)
+    cd = None if cond is None else np.repeat(cond, case.particles, axis=0).astype(np.float64)
+    ref = orc.backbone_apply(case.spec, orc.cast_tree(params, np.float64), xT.astype(np.float64), t.astype(np.float64), cd)
+    r32 = orc.backbone_apply(case.spec, params, xT, t.astype(np.float32), None if cd is None else cd.astype(np.float32))
+    model = H.product_model(case, params)
+    x = torch.from_numpy(xT).cuda()
+    c = None if cond is None else torch.from_numpy(cond).cuda()
+    got = model(x, torch.from_numpy(t).cuda(), c, particles=case.particles if case.particles > 1 else None)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    e, e32 = H.rel_err(got, ref), H.rel_err(r32, ref)
+    print(f"{case.name}: eval rel err {e:.2e} (numpy f32 {e32:.2e}), rms {H.rms_err(got, ref):.2e}")
+    assert got.shape == ref.shape and e <= 1e-5 and H.rms_err(got, ref) <= max(1e-6, 2.0 * H.rms_err(r32, ref))
+
+
+@pytest.mark.parametrize("impl", ["partitionable", "legacy"])
+def test_uniform_randint_bit_exact(impl):
+    import torch
+    from flowrl_hip import random as fr
+    key = tf.prng_key(20240)
+    kt = torch.from_numpy(key).cuda()
+    for shape, lo, hi in (((1000, 1), 1, 6), ((777,), 0, 1000), ((5, 3), -7, 9), ((64,), 4, 4), ((300000,), 1, 21)):
+        got = fr.randint(kt, shape, lo, hi, impl).cpu().numpy()
+        assert np.array_equal(got, tf.randint(key, shape, lo, hi, impl)), (shape, lo, hi)
+    for shape, lo, hi in (((1000, 1), 1e-3, 0.9946), ((4097,), 0.0, 1.0), ((3, 5), -2.0, 3.0)):
+        got = fr.uniform(kt, shape, lo, hi, impl).cpu().numpy()
+        assert np.array_equal(got, tf.uniform(key, shape, lo, hi, impl)), (shape, lo, hi)
+
+
+def test_add_noise_all_three_models():
+    """rng in -> (rng, xt, t, eps / vel) out as ddpm.py:164-171, continuous_ddpm.py:107-115, cnf.py:85-90 compute them."""
+    import torch
+    import flowrl_hip as fh
+    key = tf.prng_key(99)
+    kt = torch.from_numpy(key).cuda()
+    rng = np.random.default_rng(3)
+    B, A = 500, 6
+    x0 = rng.standard_normal((B, A)).astype(np.float32)
+    x1 = rng.standard_normal((B, A)).astype(np.float32)
+    # --- DDPM
+    c = H.Case("an-ddpm", "ddpm", A=A, S=0, T=5, B=B)
+    m = H.product_model(c, H.make_inputs(c)[0])
+    r, xt, t, eps = m.add_noise(kt, torch.from_numpy(x0).cuda())
+    k0, kt_, kn = tf.split(key, 3)
+    t_ref, eps_ref = tf.randint(kt_, (B, 1), 1, 6), tf.normal(kn, (B, A))
+    assert np.array_equal(r.cpu().numpy(), k0) and np.array_equal(t.cpu().numpy(), t_ref)
+    assert np.abs(eps.cpu().numpy() - eps_ref).max() <= 4e-7 * max(1.0, np.abs(eps_ref).max())
+    tables = orc.ddpm_tables(5, "vp", dtype=np.float32)
+    want = orc.ddpm_add_noise([v.astype(np.float64) for v in tables], x0.astype(np.float64), t_ref, eps.cpu().numpy().astype(np.float64))
+    assert H.rel_err(xt.cpu().numpy(), want) <= 2e-6
+    # --- ContinuousDDPM (cosine and linear)
+    for sched, tmax in (("cosine", 0.9946), ("linear", 1.0)):
+        c = H.Case("an-cddpm", "cddpm", A=A, S=0, T=5, B=B, temb="learnable_fourier", schedule=sched)
+        m = H.product_model(c, H.make_inputs(c)[0])
+        r, xt, t, eps = m.add_noise(kt, torch.from_numpy(x0).cuda())
+        t_ref = tf.uniform(kt_, (B, 1), 1e-3, tmax)
+        assert np.array_equal(r.cpu().numpy(), k0) and np.array_equal(t.cpu().numpy(), t_ref)
+        e_np = eps.cpu().numpy()
+        want = orc.continuous_add_noise(sched, x0.astype(np.float64), t_ref.astype(np.float64), e_np.astype(np.float64))
+        # sigma = sqrt(1 - alpha^2) cancels in float32 near t = epsilon (alpha -> 1): float32 itself is 1e-6..6e-6 off there,
+        # the reference included -> the bar is 4 x the float32 oracle's own deviation
+        w32 = orc.continuous_add_noise(sched, x0, t_ref, e_np)
+        assert H.rel_err(xt.cpu().numpy(), want) <= max(2e-6, 4.0 * H.rel_err(w32, want)), sched
+    # --- CNF
+    c = H.Case("an-cnf", "cnf", A=A, S=0, T=5, B=B, temb=None, clip=False)
+    m = H.product_model(c, H.make_inputs(c)[0])
+    r, xt, t, vel = m.linear_interpolation(kt, torch.from_numpy(x0).cuda(), torch.from_numpy(x1).cuda())
+    k0b, ktb = tf.split(key, 2)
+    t_ref = tf.uniform(ktb, (B, 1), 0.0, 1.0)
+    assert np.array_equal(r.cpu().numpy(), k0b) and np.array_equal(t.cpu().numpy(), t_ref)
+    wx, wv = orc.linear_interpolation(x0.astype(np.float64), x1.astype(np.float64), t_ref.astype(np.float64))
+    assert H.rel_err(xt.cpu().numpy(), wx) <= 2e-6 and H.rel_err(vel.cpu().numpy(), wv) <= 1e-6
+
+
+@pytest.mark.parametrize("solver,sample_xt,N", [("ddpm", True, 4), ("ddim", True, 1), ("ddpm", False, 3)])
+def test_onestep_sample(solver, sample_xt, N):
+    """DDPM.onestep_sample (ddpm.py:223-276) end to end against the oracle chain on the oracle's draws for the same key."""
+    import torch
+    case = H.Case("onestep", "ddpm", A=3, S=11, T=5, B=200, seed=31)
+    params, x0, cond, _ = H.make_inputs(case)
+    key = tf.prng_key(4321)
+    model = H.product_model(case, params)
+    t_in = np.random.default_rng(8).integers(1, 6, size=(case.B, 1)).astype(np.int32)
+    out = model.onestep_sample(torch.from_numpy(key).cuda(), torch.from_numpy(x0).cuda(), torch.from_numpy(cond).cuda(), False, N, solver,
+                               sample_xt, None if sample_xt else torch.from_numpy(t_in).cuda())
+    torch.cuda.synchronize()
+    rng_o, rep, xt, rep_t1, t, eps_theta = [v.cpu().numpy() for v in out]
+    # oracle: same split sequence (ddpm.py:236), same draws
+    k_rng, k_sample, k_noise, _ = tf.split(key, 4)
+    tables64 = [v.astype(np.float64) for v in orc.ddpm_tables(5, "vp", dtype=np.float32)]
+    if sample_xt:
+        _, kt_, kn = tf.split(k_sample, 3)
+        t_ref = tf.randint(kt_, (case.B, 1), 1, 6)
+        xt_ref = orc.ddpm_add_noise(tables64, x0.astype(np.float64), t_ref, tf.normal(kn, x0.shape).astype(np.float64))
+    else:
+        t_ref, xt_ref = t_in, x0.astype(np.float64)
+    assert np.array_equal(rng_o, k_rng) and np.array_equal(t, t_ref)
+    assert H.rel_err(xt, xt_ref) <= 2e-6
+    eps_ref = orc.backbone_apply(case.spec, orc.cast_tree(params, np.float64), xt.astype(np.float64), t_ref.astype(np.float64), cond.astype(np.float64))
+    assert H.rel_err(eps_theta, eps_ref) <= 1e-5
+    noise = tf.normal(k_noise, (case.B, N, case.A)).astype(np.float64)
+    rep_ref, rt1_ref = orc.ddpm_onestep_update(tables64, xt.astype(np.float64), eps_theta.astype(np.float64), t_ref, N, noise, solver=solver,
+                                               clip_sampler=True, x_min=-1.0, x_max=1.0)
+    assert rep.shape == (case.B, N, case.A) and np.array_equal(rep_t1, rt1_ref)
+    assert H.rel_err(rep, rep_ref) <= 5e-6
+
+
+def test_losses():
+    """jit_update_ddpm / jit_update_continuous_ddpm / jit_update_flow_matching's loss value and its cotangent."""
+    import torch
+    from flowrl_hip.flow.cnf import flow_matching_loss
+    from flowrl_hip.flow.continuous_ddpm import continuous_ddpm_loss
+    from flowrl_hip.flow.ddpm import ddpm_loss
+    key = tf.prng_key(5)
+    kt = torch.from_numpy(key).cuda()
+    rng = np.random.default_rng(12)
+    for case, fn in ((H.Case("loss-ddpm", "ddpm", A=3, S=11, T=5, B=256, seed=41), ddpm_loss),
+                     (H.Case("loss-cddpm", "cddpm", A=6, S=17, T=20, B=256, temb="learnable_fourier", schedule="cosine", seed=42), continuous_ddpm_loss),
+                     (H.Case("loss-fm", "cnf", A=8, S=39, T=10, B=256, temb=None, clip=False, hidden=(512, 512), act="gelu_tanh", seed=43), flow_matching_loss)):
+        params, xa, cond, _ = H.make_inputs(case)
+        model = H.product_model(case, params)
+        c = torch.from_numpy(cond).cuda()
+        if case.kind == "cnf":
+            xb = rng.standard_normal(xa.shape).astype(np.float32)
+            _, loss, aux = fn(kt, model, torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda(), c)
+            pred, target, g = aux["vel_pred"], aux["vel"], aux["g_vel_pred"]
+        else:
+            _, loss, aux = fn(kt, model, torch.from_numpy(xa).cuda(), c)
+            pred, target, g = aux["eps_pred"], aux["eps"], aux["g_eps_pred"]
+        torch.cuda.synchronize()
+        xt, t = aux["xt"].cpu().numpy(), aux["t"].cpu().numpy()
+        pred_ref = orc.backbone_apply(case.spec, orc.cast_tree(params, np.float64), xt.astype(np.float64), t.astype(np.float64), cond.astype(np.float64))
+        assert H.rel_err(pred.cpu().numpy(), pred_ref) <= 1e-5, case.name
+        l_ref, g_ref = orc.mse(pred.cpu().numpy().astype(np.float64), target.cpu().numpy().astype(np.float64))
+        assert abs(float(loss) - l_ref) <= 1e-6 * max(1.0, abs(l_ref)), case.name
+        assert np.abs(g.cpu().numpy() - g_ref).max() <= 1e-6 * np.abs(g_ref).max(), case.name

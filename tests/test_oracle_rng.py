@@ -96,3 +96,28 @@ def test_sampler_key_chain_protocol():
         for j in range(4):
             r = tf.split(r, 2, impl)[0]
         assert np.array_equal(rng3, r)
+
+
+# ---- uniform / randint (round 2: the t draws of add_noise / linear_interpolation) --------------------------------
+def test_uniform_and_randint_restatements():
+    """PARITY UNPINNED above random_bits (no published vector quoted).  Structural known answers of the published
+    algorithm: a power-of-two span makes the multiplier 0, so randint reduces to (lower bits mod span); every value is in
+    range; uniform is the mantissa trick scaled into [minval, maxval)."""
+    import threefry_oracle as tf
+    key = tf.prng_key(7)
+    for impl in ("partitionable", "legacy"):
+        r = tf.randint(key, (1000,), 3, 3 + 8, impl)
+        k1, k2 = tf.split(key, 2, impl)
+        assert np.array_equal(r, 3 + (tf.random_bits(k2, (1000,), impl) % np.uint32(8)).astype(np.int32))
+        r5 = tf.randint(key, (4000, 1), 1, 6, impl)           # DDPM.add_noise with steps = 5
+        assert r5.dtype == np.int32 and r5.min() == 1 and r5.max() == 5
+        counts = np.bincount(r5.ravel(), minlength=6)[1:]
+        assert (np.abs(counts - 800) < 120).all()
+        hi, lo = tf.random_bits(k1, (4000, 1), impl).astype(np.uint64), tf.random_bits(k2, (4000, 1), impl).astype(np.uint64)
+        want = 1 + (((hi % 5) * ((2 ** 32) % 5) + lo % 5) % 5)     # exact integer arithmetic: no wrap happens for span 5
+        assert np.array_equal(r5.astype(np.uint64), want)
+        assert (tf.randint(key, (10,), 4, 4, impl) == 4).all()      # maxval <= minval -> minval
+        u = tf.uniform(key, (4000,), 1e-3, 0.9946, impl)
+        assert u.dtype == np.float32 and u.min() >= np.float32(1e-3) and u.max() < np.float32(0.9946)
+        f = ((tf.random_bits(key, (4000,), impl) >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1)
+        assert np.array_equal(u, np.maximum(np.float32(1e-3), f * np.float32(np.float32(0.9946) - np.float32(1e-3)) + np.float32(1e-3)))
