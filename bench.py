@@ -199,15 +199,22 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     return e0.elapsed_time(e1) / iters, flops_alg - kernel_only_ms.hoisted, flops_exec.value
 
 
+TRAFFIC_PROFILE = "profiles/r02_prof_cfg2_default/pmc_summary.json"
+
+
 def pmc_traffic_bytes(workload, w):
-    """HBM bytes per launch of the sampler kernel from the committed rocprofv3 PMC passes (scripts/prof.sh ->
-    profiles/r01_prof_b/pmc_summary.json; cfg2 at its full batch only): 2 x FETCH_SIZE (gfx950 half-count
-    correction, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KiB.  None when no profile matches."""
-    f = ROOT / "profiles" / "r01_prof_b" / "pmc_summary.json"
+    """HBM bytes per launch of the sampler kernel from the COMMITTED rocprofv3 PMC passes (scripts/prof_r2.sh ->
+    profiles/r02_prof_cfg2_default/pmc_summary.json; cfg2 at its full batch only): 2 x FETCH_SIZE (gfx950 half-count
+    correction, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KiB.  Not measured in this run (PMC collection needs
+    the profiler): the bench line names the file in roofline.traffic_source.  None when no profile matches."""
+    f = ROOT / TRAFFIC_PROFILE
     if workload != "cfg2" or w["B"] != WORKLOADS["cfg2"]["B"] or not f.exists():
         return None
     pm = json.loads(f.read_text())
-    return (2.0 * pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0
+    k = [v for name, v in pm.items() if "frl_sampler_rs_kernel" in name]
+    if not k or "FETCH_SIZE" not in k[0] or "WRITE_SIZE" not in k[0]:
+        return None
+    return (2.0 * k[0]["FETCH_SIZE"]["mean"] + k[0]["WRITE_SIZE"]["mean"]) * 1024.0
 
 
 def cpu_baseline(w, budget_s=15.0):
@@ -463,6 +470,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": None if (vjp or args.act or args.layers or args.dtype != "f32") else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",
+                         "traffic_source": f"committed rocprofv3 PMC passes ({TRAFFIC_PROFILE}), not measured in this run",
                          "algorithmic_hbm_bytes": B * (4 * (2 * A + (T * A if (w["kind"] != "cnf" and args.rng == "none") else 0)) + 4 * S // w["particles"]),
                          "kernel": kname, "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_hoisted_not_credited": getattr(kernel_only_ms, "hoisted", 0.0) * (3.0 if vjp else 1.0),
