@@ -15,6 +15,8 @@ static __device__ __align__(256) unsigned char scratch[FRL_STATIC_WS_BYTES];
 
 namespace frl {
 
+constexpr int FRL_ACT_IDENTITY_BUILD = 6;     // = FRL_ACT_IDENTITY of frl_device.h: the kernels' post-activation-LayerNorm units
+
 static thread_local char g_err[512] = "";
 
 // Device address of `scratch` on the CURRENT device, resolved once per device.
@@ -46,6 +48,7 @@ void set_error(const char* fmt, ...) {
 
 // f32 network kernel dispatch: latency build for small batches, throughput build otherwise
 static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStream_t stream) {
+  if (a.ln_post_act != 0) act = FRL_ACT_IDENTITY_BUILD;     // post-activation LayerNorm: the pass applies the activation itself
   const long long ntiles = (a.B + 31) / 32;
   const long long cus = device_cus();
   bool lat = false;
@@ -71,6 +74,7 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
       case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, tile_rows, stream);
       case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, tile_rows, stream);
       case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, tile_rows, stream);
+      case FRL_ACT_IDENTITY_BUILD: return launch_sampler_lat_act<FRL_ACT_IDENTITY_BUILD>(a, tile_rows, stream);
       default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, tile_rows, stream);
     }
   }
@@ -80,6 +84,7 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
     case FRL_ACT_RELU: return launch_sampler_rs_act<FRL_ACT_RELU>(a, stream);
     case FRL_ACT_GELU_TANH: return launch_sampler_rs_act<FRL_ACT_GELU_TANH>(a, stream);
     case FRL_ACT_TANH: return launch_sampler_rs_act<FRL_ACT_TANH>(a, stream);
+    case FRL_ACT_IDENTITY_BUILD: return launch_sampler_rs_act<FRL_ACT_IDENTITY_BUILD>(a, stream);
     default: return launch_sampler_rs_act<FRL_ACT_ELU>(a, stream);
   }
 }
@@ -114,7 +119,7 @@ static int validate_desc(const FrlDesc* d) {
   if (d->clip && !(d->x_min <= d->x_max)) { set_error("clip range [%g, %g] invalid", d->x_min, d->x_max); return FRL_EINVAL; }
   if (d->dtype != FRL_DTYPE_F32 && d->dtype != FRL_DTYPE_BF16) { set_error("dtype %d invalid", d->dtype); return FRL_EINVAL; }
   if (d->tile_policy < FRL_TILE_AUTO || d->tile_policy > FRL_TILE_LATENCY_16) { set_error("tile_policy %d invalid", d->tile_policy); return FRL_EINVAL; }
-  if (d->layer_norm != 0 && d->layer_norm != 1) { set_error("layer_norm %d invalid", d->layer_norm); return FRL_EINVAL; }
+  if (d->layer_norm < 0 || d->layer_norm > FRL_LN_POST_ACT) { set_error("layer_norm %d invalid (0, FRL_LN_PRE_ACT, FRL_LN_POST_ACT)", d->layer_norm); return FRL_EINVAL; }
   if (d->layer_norm) {
     if (d->dtype != FRL_DTYPE_F32) { set_error("layer_norm: f32 kernel only"); return FRL_EUNSUPPORTED; }
   }
@@ -338,6 +343,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.ws_ln = desc->layer_norm ? ws + pl.off_ln : nullptr;
+  a.ln_post_act = desc->layer_norm == FRL_LN_POST_ACT ? 1 + desc->act : 0;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.NE = pl.NE; a.AO = pl.AO;
   if (pl.hoist) a.C = 0;
@@ -822,6 +828,7 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
   a.ws_ln = desc->layer_norm ? ws + pl.off_ln : nullptr;
+  a.ln_post_act = desc->layer_norm == FRL_LN_POST_ACT ? 1 + desc->act : 0;
   a.B = pl.B; a.particles = 1; a.A = pl.A; a.C = 0; a.T = 1; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.NE = 1; a.AO = pl.AO;
   a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));

@@ -47,10 +47,16 @@ struct Geo<16> {
 // ---- activations (flowrl/functional/activation.py:8-18; flax gelu tanh form) -------------------
 // exp via v_exp_f32 and reciprocal via v_rcp_f32 (1 ulp each); every form below is free of
 // cancellation so the relative error stays at a few ulp over the whole range.
+// Internal activation id of the post-activation-LayerNorm builds (FQL's MLP, fql/network.py:26-30: Dense -> act -> LayerNorm):
+// the LayerNorm pass applies the real activation in place before it normalises, every consumer then takes the tile as it is.
+#define FRL_ACT_IDENTITY 6
+
 template <int ACT>
 __device__ __forceinline__ float act_fn(float x) {
   constexpr float LOG2E = 1.4426950408889634f;
-  if constexpr (ACT == FRL_ACT_MISH) {
+  if constexpr (ACT == FRL_ACT_IDENTITY) {
+    return x;
+  } else if constexpr (ACT == FRL_ACT_MISH) {
     // x * tanh(softplus(x)) == x * n / (n + 2),  n = e^x (e^x + 2)
     const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -88.0f, 20.0f) * LOG2E);
     const float n = e * (e + 2.0f);
@@ -81,7 +87,9 @@ __device__ __forceinline__ float act_fn(float x) {
 template <int ACT>
 __device__ __forceinline__ f32x2 act_fn2(f32x2 x) {
   constexpr float LOG2E = 1.4426950408889634f;
-  if constexpr (ACT == FRL_ACT_MISH) {
+  if constexpr (ACT == FRL_ACT_IDENTITY) {
+    return x;
+  } else if constexpr (ACT == FRL_ACT_MISH) {
     f32x2 c = {__builtin_amdgcn_fmed3f(x[0], -88.0f, 20.0f), __builtin_amdgcn_fmed3f(x[1], -88.0f, 20.0f)};
     c = c * LOG2E;
     const f32x2 e = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
@@ -106,6 +114,18 @@ __device__ __forceinline__ f32x2 act_fn2(f32x2 x) {
     return x * r;
   } else {
     return f32x2{act_fn<ACT>(x[0]), act_fn<ACT>(x[1])};
+  }
+}
+
+// activation chosen at run time (uniform): the in-place activation of a post-activation LayerNorm pass
+__device__ __forceinline__ float act_rt(int act, float x) {
+  switch (act) {
+    case FRL_ACT_MISH: return act_fn<FRL_ACT_MISH>(x);
+    case FRL_ACT_SILU: return act_fn<FRL_ACT_SILU>(x);
+    case FRL_ACT_RELU: return act_fn<FRL_ACT_RELU>(x);
+    case FRL_ACT_GELU_TANH: return act_fn<FRL_ACT_GELU_TANH>(x);
+    case FRL_ACT_TANH: return act_fn<FRL_ACT_TANH>(x);
+    default: return act_fn<FRL_ACT_ELU>(x);
   }
 }
 

@@ -140,6 +140,7 @@ struct KArgs {
   int rng_impl;
   long long rng_off, rng_total;           // first chain of this call in the unsharded batch / its chain count (draw indices)
   const float* ws_ln;                     // [L][2][H] LayerNorm scale | bias of every hidden layer, or NULL (no LayerNorm)
+  int ln_post_act;                        // 0: Dense -> LayerNorm -> act; 1 + FRL_ACT_*: Dense -> act -> LayerNorm (identity-activation build)
   int lat_tb_global;                      // latency kernel: time-bias rows read from the workspace, not staged in LDS
   const float* state_bias;                // MODE_EVAL: [n_states][H] Dense_0 accumulator init per STATE (hoisted obs rows) or NULL
   int w0p_bytes;

@@ -190,6 +190,10 @@ frl_sampler_lat_kernel(const KArgs a) {
       // then the variance about it, each a register sum + lane-group exchange + four per-wave partials through LDS
       // (two extra barriers per layer; the partial buffers alternate, so no third one is needed)
       auto ln_pass = [&](int l) {
+        if (a.ln_post_act != 0) {      // FQL's order (fql/network.py:26-30): the activation first, in place; consumers are identity
+          const int act = a.ln_post_act - 1;
+          sfor<NBW>([&](auto JI) { constexpr int jb = decltype(JI)::value; sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; acc[jb][r] = act_rt(act, acc[jb][r]); }); });
+        }
         // every level of these sums is a fixed pairwise tree (four interleaved register partials, the lane-group
         // butterfly, then the four waves' partials as (w0 + w1) + (w2 + w3)): error growth like numpy's pairwise mean
         float p1[4] = {0.0f, 0.0f, 0.0f, 0.0f};

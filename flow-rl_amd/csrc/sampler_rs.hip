@@ -99,6 +99,10 @@ frl_sampler_rs_kernel(const KArgs a) {
   // Dense -> LayerNorm -> act): mean and E[x^2] over the lane's own registers, combined across the 64 / TR lanes that
   // hold the other feature rows of the same chain; eps = 1e-6.
   auto ln_pass = [&](acc_t (&Q)[NB], const float* sl) {
+    if (a.ln_post_act != 0) {      // FQL's order (fql/network.py:26-30): the activation first, in place; consumers are identity
+      const int act = a.ln_post_act - 1;
+      sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; Q[b][r] = act_rt(act, Q[b][r]); }); });
+    }
     // eight interleaved partial sums combined as a tree (then the lane-group butterfly): the rounding error grows with
     // NB NR / 8 + 3 additions instead of NB NR, i.e. no worse than numpy's pairwise mean
     float p1[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -417,9 +421,16 @@ static int launch_inst_v(const KArgs& a, hipStream_t stream) {
 // pass, so that the hoisted cfg4 path does not carry their code either.
 template <int TR, int H, int ACT, int NRX, int CKMAX>
 static int launch_inst(const KArgs& a, hipStream_t stream) {
+  if constexpr (ACT == FRL_ACT_IDENTITY) {     // the identity-activation unit only serves post-activation LayerNorm (EXT 2)
+    if (a.ws_ln == nullptr || a.ln_post_act == 0) { set_error("identity-activation build without a post-activation LayerNorm"); return FRL_EINVAL; }
+    return launch_inst_v<TR, H, ACT, NRX, CKMAX, 2>(a, stream);
+  }
   if (a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 2>(a, stream);
-  if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 1>(a, stream);
-  return launch_inst_v<TR, H, ACT, NRX, CKMAX, 0>(a, stream);
+  if constexpr (ACT != FRL_ACT_IDENTITY) {
+    if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 1>(a, stream);
+    return launch_inst_v<TR, H, ACT, NRX, CKMAX, 0>(a, stream);
+  }
+  return FRL_EINVAL;
 }
 
 template <int ACT>

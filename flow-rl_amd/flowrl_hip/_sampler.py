@@ -123,7 +123,8 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
         raise ValueError(f"tile_policy {tile_policy!r}: 'auto', 'throughput' (one wave per tile), 'latency' (four waves per tile) or 'latency32' / 'latency16' (that build on 32- / 16-chain tiles)")
     d.tile_policy = _lib.FRL_TILE[tile_policy]
     d.rng_impl = int(rng_impl)
-    d.layer_norm = 1 if pred.layer_norm else 0     # Dense -> LayerNorm -> act (mlp.py:26-29)
+    # Dense -> LayerNorm -> act (mlp.py:26-29), or FQL's Dense -> act -> LayerNorm (fql/network.py:26-30)
+    d.layer_norm = (2 if getattr(pred, "ln_after_act", False) else 1) if pred.layer_norm else 0
     return d
 
 

@@ -4,7 +4,8 @@ No arithmetic lives here: these classes only describe the backbone so that the p
 ``Model.create`` (flowrl/module/model.py:31-60) can be handed, leaf by leaf and in place, to the
 fused HIP kernel.  Names follow the reference:
 
-  MLP                          flowrl/module/mlp.py:10-34   (FQL variant: agent/offline/fql/network.py:10-35)
+  MLP                          flowrl/module/mlp.py:10-34 (Dense -> [LayerNorm] -> act); with ln_after_act=True FQL's
+                               variant agent/offline/fql/network.py:10-35 (Dense -> act -> [LayerNorm])
   PositionalEmbedding          flowrl/module/time_embedding.py:6-16
   LearnableFourierEmbedding    flowrl/module/time_embedding.py:19-27
   DDPMBackbone / FlowBackbone  flowrl/flow/ddpm.py:70-95 / flowrl/flow/cnf.py:17-42
@@ -45,6 +46,8 @@ class MLP:
     activation: Union[str, Callable] = "relu"
     layer_norm: bool = False
     dropout: Optional[float] = None
+    ln_after_act: bool = False      # FQL's MLP (agent/offline/fql/network.py:26-30): Dense -> act -> LayerNorm instead of
+                                    # flowrl/module/mlp.py:26-29's Dense -> LayerNorm -> act; only read when layer_norm is set
 
     @property
     def act_name(self) -> str:

@@ -76,6 +76,10 @@ extern "C" {
 #define FRL_RNG_THREEFRY_PARTITIONABLE 1 /* in-kernel threefry2x32, jax_threefry_partitionable=True (jax >= 0.5.0 default) */
 #define FRL_RNG_THREEFRY_LEGACY 2        /* in-kernel threefry2x32, the pre-0.5.0 default key / counter layout           */
 
+#define FRL_LN_NONE 0
+#define FRL_LN_PRE_ACT 1  /* flowrl/module/mlp.py:26-29 */
+#define FRL_LN_POST_ACT 2 /* flowrl/agent/offline/fql/network.py:26-30 */
+
 #define FRL_DTYPE_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the bit-faithful path */
 #define FRL_DTYPE_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16) operands, f32 accumulate / activations / chain state: stated tolerance */
 
@@ -107,8 +111,9 @@ typedef struct FrlDesc {
   int32_t tile_policy;  /* FRL_TILE_*: which f32 kernel build runs the chains (results agree to rounding) */
   int32_t rng_impl;     /* FRL_RNG_*: with a threefry layout, bufs.rng_key replaces bufs.noise and the call also produces
                            the rng the reference's sample() returns (bufs.rng_out), for every solver */
-  int32_t layer_norm;   /* 1: the predictor MLP is Dense -> LayerNorm -> act (MLP(layer_norm=True), mlp.py:26-29; flax LayerNorm:
-                           eps 1e-6, scale and bias; the variance is taken about the mean) — f32 builds, forward only */
+  int32_t layer_norm;   /* FRL_LN_PRE_ACT (1): the predictor MLP is Dense -> LayerNorm -> act (MLP(layer_norm=True), mlp.py:26-29);
+                           FRL_LN_POST_ACT (2): Dense -> act -> LayerNorm (FQL's MLP, agent/offline/fql/network.py:26-30).
+                           flax LayerNorm: eps 1e-6, scale and bias; the variance is taken about the mean — f32 builds, forward only */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a

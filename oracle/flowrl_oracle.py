@@ -230,14 +230,17 @@ def layer_norm(p, x, eps=1e-6):
     return (x - mean) * mul + p["bias"]
 
 
-def mlp_apply(p: Dict, x, n_hidden: int, activation, has_output: bool, ln: bool = False):
+def mlp_apply(p: Dict, x, n_hidden: int, activation, has_output: bool, ln: bool = False, ln_after_act: bool = False):
     """mlp.py:25-33, dropout off: Dense -> [LayerNorm] -> act per hidden layer (layer_norm is off in all shipped
-    sampler configs; flax names the i-th LayerNorm of the module "LayerNorm_i")."""
+    sampler configs; flax names the i-th LayerNorm of the module "LayerNorm_i").  ln_after_act: FQL's MLP
+    (agent/offline/fql/network.py:26-30) puts the LayerNorm AFTER the activation."""
     for i in range(n_hidden):
         x = dense(p[f"Dense_{i}"], x)
-        if ln:
+        if ln and not ln_after_act:
             x = layer_norm(p[f"LayerNorm_{i}"], x)
         x = activation(x)
+        if ln and ln_after_act:
+            x = layer_norm(p[f"LayerNorm_{i}"], x)
     if has_output:
         x = dense(p[f"Dense_{n_hidden}"], x)
     return x
@@ -254,6 +257,7 @@ class BackboneSpec:
     cond_hidden: Optional[Sequence[int]] = None     # cond_embedding MLP hidden dims (dacer.py:263-266) or None
     predictor_name: str = "noise_predictor"         # "vel_predictor" for FlowBackbone
     layer_norm: bool = False                        # MLP(layer_norm=True) predictor (mlp.py:27-28)
+    ln_after_act: bool = False                      # FQL's MLP: Dense -> act -> LayerNorm (fql/network.py:26-30)
     bf16_operands: bool = False                     # emulate the bf16-MFMA variant: predictor Dense operands rounded to
                                                     # bf16 (RNE), products / sums / biases / time slice / activations exact
 
@@ -299,7 +303,8 @@ def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
         inputs = np.concatenate([x, time, condition], axis=-1)
     else:
         inputs = np.concatenate([x, time], axis=-1)
-    return mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, has_output=True, ln=spec.layer_norm)
+    return mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, has_output=True, ln=spec.layer_norm,
+                     ln_after_act=spec.ln_after_act)
 
 
 # --------------------------------------------------------------------------- #

@@ -32,6 +32,7 @@ class Case:
     bf16: bool = False             # bf16-MFMA variant (product) / bf16-operand emulation (oracle)
     tile: str = "auto"             # FrlDesc.tile_policy of the product run: auto | throughput | latency
     ln: bool = False               # MLP(layer_norm=True) predictor: Dense -> LayerNorm -> act (mlp.py:26-29)
+    ln_post: bool = False          # with ln: FQL's order Dense -> act -> LayerNorm (fql/network.py:26-30)
 
     @property
     def spec(self):
@@ -39,7 +40,7 @@ class Case:
                                 time_embedding=self.temb, time_dim=64,
                                 cond_hidden=[128, 128] if self.cond_embed else None,
                                 predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor",
-                                bf16_operands=self.bf16, layer_norm=self.ln)
+                                bf16_operands=self.bf16, layer_norm=self.ln, ln_after_act=self.ln_post)
 
 
 def make_inputs(c: Case):
@@ -119,7 +120,7 @@ def product_model(c: Case, params, device="cuda"):
         te = fh.PositionalEmbedding(output_dim=64)
     elif c.temb == "learnable_fourier":
         te = fh.LearnableFourierEmbedding(output_dim=64)
-    mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act, layer_norm=c.ln)
+    mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act, layer_norm=c.ln, ln_after_act=c.ln_post)
     ce = fh.MLP(hidden_dims=[128, 128], activation=c.act) if c.cond_embed else None
     tparams = fh.tree_from_numpy(params, device)
     inputs = (np.ones((1, c.A)), np.zeros((1, 1)), np.ones((1, c.S)) if c.S > 0 else None)

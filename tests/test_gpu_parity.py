@@ -306,6 +306,12 @@ def test_layer_norm_backbones():
         H.Case("ln-cnf-512", "cnf", A=8, S=39, T=6, B=100, hidden=(512, 512, 512), act="gelu_tanh", temb=None, clip=False, ln=True, seed=43),
         H.Case("ln-one-hidden-relu", "ddpm", A=2, S=0, T=6, B=33, hidden=(256,), act="relu", schedule="linear", ln=True, seed=44),
         H.Case("ln-dpmpp2m", "cddpm", A=3, S=11, T=6, B=64, temb="learnable_fourier", schedule="cosine", solver="dpm++2m", ln=True, seed=45),
+        # FQL's MLP puts the LayerNorm AFTER the activation (agent/offline/fql/network.py:26-30): identity-activation builds
+        H.Case("lnpost-fql-512x4", "cnf", A=8, S=39, T=6, B=100, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None, clip=False,
+               ln=True, ln_post=True, seed=46),
+        H.Case("lnpost-ddpm-mish", "ddpm", A=3, S=11, T=5, B=200, ln=True, ln_post=True, seed=47),
+        H.Case("lnpost-particles-relu", "cddpm", A=6, S=64, T=6, B=10 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
+               act="relu", ln=True, ln_post=True, seed=48),
     ]
     # LayerNorm multiplies a layer's rounding noise by rstd * scale; on the ill-conditioned cosine case the float32 numpy
     # oracle is itself 2.8e-5 from float64.  Every build meets the common bar (4 x float32's own deviation): the
