@@ -452,9 +452,11 @@ static void fill_bwd_args(const FrlDesc* desc, const FrlParams* params, const Pl
   b.n_part = bf16 ? bp16.n_part : bp.n_part;
   b.k0_rows = bf16 ? 32 : bp.k0_rows;
   b.ge_stride = bf16 ? 256 : bp.ge_stride;
+  b.dw_cond = a.cond; b.dw_C = pl.C;
   if (!bf16 && desc->cond_embed) {
     // the predictor sees cfeat = cond_embedding(obs) (n_states, 128), computed once per state into the workspace
     a.cond = ws + pl.off_cfeat;
+    b.dw_cond = a.cond;
     b.ws_w0cq = ws + bp.off_w0cq;
     b.gcf = ws + bp.off_gcf;
   }
@@ -573,7 +575,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   if (desc->cond_embed) {
     // dL/dcfeat (per chain, summed over steps by the sweep) -> the two embedding layers (bufs.cond = the raw observations)
     rc = launch_cond_embed_bwd(desc->act, bufs->cond, desc->n_states, desc->particles, desc->cond_in_dim, params->cond_kernel[0],
-                               params->cond_bias[0], params->cond_kernel[1], params->cond_bias[1], b.gcf, ws + bp.off_ceb,
+                               params->cond_bias[0], params->cond_kernel[1], params->cond_bias[1], b.gcf, COND_EMBED_DIM, ws + bp.off_ceb,
                                bufs->grad_cond_kernel[0], bufs->grad_cond_bias[0], bufs->grad_cond_kernel[1], bufs->grad_cond_bias[1], stream);
     if (rc != FRL_OK) return rc;
   }
@@ -836,6 +838,183 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
   a.wl_raw = params->kernel[pl.L];
   return launch_f32_network(a, desc->act, desc->tile_policy, stream);
+}
+
+// ---- single-evaluation VJP: the evaluation under jax.grad --------------------------------------------------------------
+struct EvalBwdPlan {
+  EvalPlan e;           // carrier descriptor + forward tables (C = 0: time / condition rows hoisted into per-sample rows)
+  BwdPlan bp;           // stash, transposed images, dW slots behind them
+  int Cp;               // rows of u = [tfeat | cond] = Dp + C
+  size_t off_cfeat, off_u, off_zt, off_du, off_tsc, off_ceb, total_floats;
+};
+
+static int eval_bwd_plan(const FrlDesc* desc, EvalBwdPlan& q) {
+  int rc = eval_plan(desc, q.e);
+  if (rc != FRL_OK) return rc;
+  const Plan& pl = q.e.pl;
+  if (pl.H != 256 || pl.TR != 32) { set_error("single-evaluation VJP: 256-wide predictors only"); return FRL_EUNSUPPORTED; }
+  if (desc->layer_norm) { set_error("single-evaluation VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
+  if (desc->act != FRL_ACT_MISH && desc->act != FRL_ACT_SILU && desc->act != FRL_ACT_RELU) { set_error("single-evaluation VJP: activation %d (mish / silu / relu)", desc->act); return FRL_EUNSUPPORTED; }
+  q.Cp = q.e.Dp + q.e.C;
+  if (pl.AR > 12 || pl.A + q.Cp > 224) { set_error("single-evaluation VJP: x_dim <= 24 and x_dim + time_dim + cond_dim <= 224 required (got %d, %d)", pl.A, q.Cp); return FRL_EUNSUPPORTED; }
+  if (desc->time_embed != FRL_TEMB_NONE && desc->time_dim > 128) { set_error("single-evaluation VJP: time_dim <= 128"); return FRL_EUNSUPPORTED; }
+  q.bp.f = pl;
+  bwd_plan_finish(q.bp, 0, desc->n_states, pl.A + q.Cp);
+  size_t o = q.bp.total_floats;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+  const int D = desc->time_embed == FRL_TEMB_NONE ? 0 : desc->time_dim;
+  q.off_cfeat = take(desc->cond_embed ? (size_t)desc->n_states * COND_EMBED_DIM : 0);
+  q.off_u = take((size_t)pl.B * q.Cp);
+  q.off_zt = take((size_t)pl.B * pl.H);
+  q.off_du = take((size_t)pl.B * q.Cp);
+  q.off_tsc = take((size_t)pl.B * (4 * D + D / 2));
+  q.off_ceb = take(desc->cond_embed ? (size_t)desc->n_states * 3 * COND_EMBED_DIM : 0);
+  q.total_floats = o;
+  return FRL_OK;
+}
+
+static void fill_eval_bargs(const FrlDesc* desc, const FrlParams* params, const EvalBwdPlan& q, float* ws, BArgs& b) {
+  const Plan& pl = q.e.pl;
+  const BwdPlan& bp = q.bp;
+  memset(&b, 0, sizeof(b));
+  KArgs& a = b.k;
+  for (int l = 1; l < pl.L; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; b.wt[l - 1] = ws + bp.off_wt[l - 1]; }
+  a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
+  a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
+  a.B = pl.B; a.particles = 1; a.A = pl.A; a.C = 0; a.T = 1; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
+  a.NE = 1; a.AO = pl.AO;
+  a.w0p_bytes = (int)(pl.w0p_rows * pl.H * sizeof(float));
+  a.mode = MODE_EVAL;
+  a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
+  a.state_bias = ws + q.off_zt;
+  b.ws_wlt = ws + bp.off_wlt; b.ws_w0xq = ws + bp.off_w0xq;
+  b.hd = ws + bp.off_hd; b.ad = ws + bp.off_ad; b.gd = ws + bp.off_gd; b.ge = ws + bp.off_ge;
+  b.Dp = 0;
+  b.n_ts = bp.n_ts;
+  b.part = ws + bp.off_part; b.n_part = bp.n_part;
+  b.k0_rows = bp.k0_rows; b.ge_stride = bp.ge_stride;
+  b.dw_cond = ws + q.off_u; b.dw_C = q.Cp;
+}
+
+size_t frl_net_eval_bwd_workspace_bytes(const FrlDesc* desc) {
+  EvalBwdPlan q;
+  if (eval_bwd_plan(desc, q) != FRL_OK) return 0;
+  return q.total_floats * sizeof(float);
+}
+
+static int eval_check_params(const FrlDesc* desc, const FrlParams* params) {
+  for (int l = 0; l <= desc->n_hidden; ++l)
+    if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->time_embed != FRL_TEMB_NONE) {
+    for (int k = 0; k < 2; ++k)
+      if (params->tmlp_kernel[k] == nullptr || params->tmlp_bias[k] == nullptr) { set_error("params.tmlp_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+    if (desc->time_embed == FRL_TEMB_FOURIER && params->time_kernel == nullptr) { set_error("params.time_kernel is NULL"); return FRL_EINVAL; }
+  }
+  if (desc->cond_embed)
+    for (int k = 0; k < 2; ++k)
+      if (params->cond_kernel[k] == nullptr || params->cond_bias[k] == nullptr) { set_error("params.cond_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+  return FRL_OK;
+}
+
+int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* workspace, size_t workspace_bytes,
+                       void* hip_stream) {
+  EvalBwdPlan q;
+  int rc = eval_bwd_plan(desc, q);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
+  const Plan& pl = q.e.pl;
+  if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (workspace_bytes < q.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B (frl_net_eval_bwd_workspace_bytes)", workspace_bytes, q.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  if (pl.B == 0) return FRL_OK;
+  if (bufs->x == nullptr || bufs->t == nullptr || bufs->out == nullptr) { set_error("bufs.x / t / out is NULL"); return FRL_EINVAL; }
+  if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
+  rc = eval_check_params(desc, params);
+  if (rc != FRL_OK) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  float* ws = (float*)workspace;
+  PArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  for (int l = 0; l <= pl.L; ++l) { pa.p.kernel[l] = params->kernel[l]; pa.p.bias[l] = params->bias[l]; }
+  pa.ws = ws; pa.plan = pl; pa.kind = FRL_KIND_CNF; pa.time_embed = FRL_TEMB_NONE;
+  rc = launch_prepare(pa, stream);
+  if (rc != FRL_OK) return rc;
+  const float* cond = bufs->cond;
+  if (desc->cond_embed) {
+    rc = launch_cond_embed(desc->act, bufs->cond, desc->n_states, desc->cond_in_dim, params->cond_kernel[0], params->cond_bias[0],
+                           params->cond_kernel[1], params->cond_bias[1], ws + q.off_cfeat, stream);
+    if (rc != FRL_OK) return rc;
+    cond = ws + q.off_cfeat;
+  }
+  rc = launch_time_rows(*desc, *params, bufs->t, cond, q.e.C, ws + q.off_u, pl.B, stream);
+  if (rc != FRL_OK) return rc;
+  rc = launch_state_bias(ws + q.off_u, pl.B, q.Cp, pl.H, params->kernel[0] + (size_t)desc->x_dim * pl.H, nullptr, ws + q.off_zt, stream);
+  if (rc != FRL_OK) return rc;
+  BArgs b;
+  fill_eval_bargs(desc, params, q, ws, b);
+  b.k.xT = bufs->x; b.k.x0 = bufs->out;
+  return launch_sampler_bwd(q.e.d, b, 1, stream);
+}
+
+int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEvalBwdBufs* bufs, void* workspace, size_t workspace_bytes,
+                     void* hip_stream) {
+  EvalBwdPlan q;
+  int rc = eval_bwd_plan(desc, q);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
+  const Plan& pl = q.e.pl;
+  if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (workspace_bytes < q.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B", workspace_bytes, q.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  if (pl.B == 0) return FRL_OK;
+  if (bufs->x == nullptr || bufs->t == nullptr || bufs->g_out == nullptr) { set_error("bufs.x / t / g_out is NULL"); return FRL_EINVAL; }
+  if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
+  rc = eval_check_params(desc, params);
+  if (rc != FRL_OK) return rc;
+  for (int l = 0; l <= desc->n_hidden; ++l)
+    if (bufs->grad_kernel[l] == nullptr || bufs->grad_bias[l] == nullptr) { set_error("bufs.grad_kernel / grad_bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->time_embed != FRL_TEMB_NONE) {
+    for (int k = 0; k < 2; ++k)
+      if (bufs->grad_tmlp_kernel[k] == nullptr || bufs->grad_tmlp_bias[k] == nullptr) { set_error("bufs.grad_tmlp_kernel / grad_tmlp_bias[%d] is NULL", k); return FRL_EINVAL; }
+    if (desc->time_embed == FRL_TEMB_FOURIER && bufs->grad_time_kernel == nullptr) { set_error("bufs.grad_time_kernel is NULL"); return FRL_EINVAL; }
+  }
+  if (desc->cond_embed)
+    for (int k = 0; k < 2; ++k)
+      if (bufs->grad_cond_kernel[k] == nullptr || bufs->grad_cond_bias[k] == nullptr) { set_error("bufs.grad_cond_kernel / grad_cond_bias[%d] is NULL", k); return FRL_EINVAL; }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  float* ws = (float*)workspace;
+  rc = launch_prepare_bwd(*params, q.bp, ws, stream);          // transposed hidden kernels, W_L^T, packed x rows of Dense_0
+  if (rc != FRL_OK) return rc;
+  BArgs b;
+  fill_eval_bargs(desc, params, q, ws, b);
+  b.xt_hist = bufs->x;                                        // T = 1: the evaluation's input is "history[0]"
+  b.g_x0 = bufs->g_out; b.g_xT = bufs->g_x; b.eps_hist = nullptr;
+  for (int l = 0; l <= pl.L; ++l) { b.grad_kernel[l] = bufs->grad_kernel[l]; b.grad_bias[l] = bufs->grad_bias[l]; }
+  b.grad_tb = bufs->grad_bias[0];                             // one "step": dL/dtb[0] IS dL/dbias_0 (tb = bias_0 in this plan)
+  rc = launch_sampler_bwd(q.e.d, b, 2, stream);               // backward sweep from the stash + dW + fixed-order reduce
+  if (rc != FRL_OK) return rc;
+  // dL/du = dL/dz_0 . kernel_0[A:]^T per sample, then the two branches that produced u = [tfeat | cond]
+  float* du = ws + q.off_du;
+  rc = launch_eval_du(b, params->kernel[0] + (size_t)desc->x_dim * pl.H, q.Cp, du, stream);
+  if (rc != FRL_OK) return rc;
+  if (desc->time_embed != FRL_TEMB_NONE) {
+    TimeBwdSampleArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.t = bufs->t; ta.du = du; ta.du_stride = q.Cp;
+    ta.time_kernel = params->time_kernel; ta.tk0 = params->tmlp_kernel[0]; ta.tb0 = params->tmlp_bias[0];
+    ta.tk1 = params->tmlp_kernel[1]; ta.tb1 = params->tmlp_bias[1];
+    ta.scratch = ws + q.off_tsc;
+    ta.g_tk0 = bufs->grad_tmlp_kernel[0]; ta.g_tb0 = bufs->grad_tmlp_bias[0]; ta.g_tk1 = bufs->grad_tmlp_kernel[1]; ta.g_tb1 = bufs->grad_tmlp_bias[1];
+    ta.g_time_kernel = bufs->grad_time_kernel;
+    ta.B = pl.B; ta.D = desc->time_dim; ta.time_embed = desc->time_embed;
+    rc = launch_time_bwd_samples(ta, stream);
+    if (rc != FRL_OK) return rc;
+  }
+  if (desc->cond_embed) {
+    rc = launch_cond_embed_bwd(desc->act, bufs->cond, desc->n_states, desc->particles, desc->cond_in_dim, params->cond_kernel[0],
+                               params->cond_bias[0], params->cond_kernel[1], params->cond_bias[1], du + q.e.Dp, q.Cp, ws + q.off_ceb,
+                               bufs->grad_cond_kernel[0], bufs->grad_cond_bias[0], bufs->grad_cond_kernel[1], bufs->grad_cond_bias[1], stream);
+    if (rc != FRL_OK) return rc;
+  }
+  return FRL_OK;
 }
 
 int frl_add_noise(int32_t kind, int64_t B, int32_t A, const float* x0, const float* e, const void* t, const float* alpha_hats,

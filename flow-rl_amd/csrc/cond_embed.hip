@@ -174,7 +174,7 @@ __device__ __forceinline__ void cact_grad(int act, float z, float& h, float& d) 
 __global__ void __launch_bounds__(128)
 frl_cond_embed_bwd_state_kernel(int act, const float* __restrict__ obs, int S, int particles, const float* __restrict__ w0,
                                 const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
-                                const float* __restrict__ gcf, float* __restrict__ scratch) {
+                                const float* __restrict__ gcf, int gcf_stride, float* __restrict__ scratch) {
   constexpr int E = COND_EMBED_DIM;
   extern __shared__ float sm[];          // obs[S] | h1[E] | dz2[E]
   float* s_obs = sm;
@@ -195,7 +195,7 @@ frl_cond_embed_bwd_state_kernel(int act, const float* __restrict__ obs, int S, i
   float h2, a2;
   cact_grad(act, z2, h2, a2);
   float g = 0.0f;
-  for (int p = 0; p < particles; ++p) g += gcf[((size_t)state * particles + p) * E + t];
+  for (int p = 0; p < particles; ++p) g += gcf[((size_t)state * particles + p) * gcf_stride + t];
   const float dz2 = g * a2;
   s_dz2[t] = dz2;
   __syncthreads();
@@ -240,15 +240,15 @@ frl_cond_embed_bwd_reduce_kernel(const float* __restrict__ obs, long long n_stat
 }
 
 int launch_cond_embed_bwd(int act, const float* obs, long long n_states, int particles, int in_dim, const float* w0, const float* b0,
-                          const float* w1, const float* b1, const float* gcf, float* scratch, float* g_w0, float* g_b0, float* g_w1,
-                          float* g_b1, hipStream_t stream) {
+                          const float* w1, const float* b1, const float* gcf, int gcf_stride, float* scratch, float* g_w0, float* g_b0,
+                          float* g_w1, float* g_b1, hipStream_t stream) {
   if (n_states <= 0) return FRL_OK;
   if (act != FRL_ACT_MISH && act != FRL_ACT_SILU && act != FRL_ACT_RELU) { set_error("cond_embedding backward: activation %d (mish / silu / relu)", act); return FRL_EUNSUPPORTED; }
   const size_t lds = sizeof(float) * ((size_t)in_dim + 2 * COND_EMBED_DIM);
   if (lds > 60000) { set_error("cond_embedding backward: observation width %d too large", in_dim); return FRL_EUNSUPPORTED; }
   if (n_states > 0x7fffffffLL) { set_error("cond_embedding backward: too many states"); return FRL_EUNSUPPORTED; }
   hipLaunchKernelGGL(frl_cond_embed_bwd_state_kernel, dim3((unsigned)n_states), dim3(COND_EMBED_DIM), lds, stream, act, obs, in_dim, particles,
-                     w0, b0, w1, b1, gcf, scratch);
+                     w0, b0, w1, b1, gcf, gcf_stride, scratch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("cond_embed bwd launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   const long long total = (long long)in_dim * COND_EMBED_DIM + COND_EMBED_DIM + (long long)COND_EMBED_DIM * COND_EMBED_DIM + COND_EMBED_DIM;

@@ -203,12 +203,13 @@ struct BwdPlan {
   size_t total_floats;
 };
 
-inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
-  plan_from_desc(d, b.f, false);
+// Second half of the backward plan: stash / image / slot layout behind the forward tables b.f (set by the caller).
+// dw_rows = rows of Dense_0's dW tile source (x rows + whatever is staged as "condition" rows for the dW kernel).
+inline int bwd_plan_finish(BwdPlan& b, int cond_embed, long long n_states, int dw_rows) {
   const Plan& p = b.f;
-  b.cond_embed = d.cond_embed ? 1 : 0;
+  b.cond_embed = cond_embed ? 1 : 0;
   b.wide = (p.AR > 4 || p.CK > 12) ? 1 : 0;
-  b.k0_rows = 32 * ((p.A + p.C + 31) / 32);
+  b.k0_rows = 32 * ((dw_rows + 31) / 32);
   if (b.k0_rows < 32) b.k0_rows = 32;
   b.ge_stride = 64 * (b.wide ? 12 : 4);
   b.n_wt = (p.B + 31) / 32;
@@ -225,11 +226,16 @@ inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
   b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
   { const long long cus = device_cus(); b.n_part = (int)(b.n_ts < cus ? b.n_ts : cus); if (b.n_part < 1) b.n_part = 1; }
   b.off_part = take((size_t)b.n_part * dw_part_layout(p.L, p.T, b.k0_rows).stride);
-  b.off_w0cq = take(d.cond_embed ? (size_t)4 * p.H * 64 : 0);
-  b.off_gcf = take(d.cond_embed ? (size_t)p.B * COND_EMBED_DIM : 0);
-  b.off_ceb = take(d.cond_embed ? (size_t)d.n_states * 3 * COND_EMBED_DIM : 0);
+  b.off_w0cq = take(cond_embed ? (size_t)4 * p.H * 64 : 0);
+  b.off_gcf = take(cond_embed ? (size_t)p.B * COND_EMBED_DIM : 0);
+  b.off_ceb = take(cond_embed ? (size_t)n_states * 3 * COND_EMBED_DIM : 0);
   b.total_floats = o;
   return 0;
+}
+
+inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
+  plan_from_desc(d, b.f, false);
+  return bwd_plan_finish(b, d.cond_embed, d.n_states, b.f.A + b.f.C);
 }
 
 struct BArgs {
@@ -244,13 +250,25 @@ struct BArgs {
   long long n_ts;
   float* part; int n_part;        // dW partial slots (DwPart layout), one per workgroup of the dW kernel
   int k0_rows, ge_stride;         // BwdPlan.k0_rows / ge_stride
+  const float* dw_cond; int dw_C; // what the dW kernel stages behind the x rows of Dense_0's tile (the chain VJP: k.cond / k.C; the
+                                  // single-evaluation VJP: u = [tfeat | cond] per sample while the sweep's own k.C is 0)
   const float* ws_w0cq;           // packed Dense_0 cond rows (4 blocks), or NULL
   float* gcf;                     // (B, 128) dL/dcfeat per chain, or NULL: written by the backward sweep of the wide build
 };
 // cond_embedding backward (csrc/cond_embed.hip): per-state chain rule, then a fixed-order sum over the states
 int launch_cond_embed_bwd(int act, const float* obs, long long n_states, int particles, int in_dim, const float* w0, const float* b0,
-                          const float* w1, const float* b1, const float* gcf, float* scratch, float* g_w0, float* g_b0, float* g_w1,
-                          float* g_b1, hipStream_t stream);
+                          const float* w1, const float* b1, const float* gcf, int gcf_stride, float* scratch, float* g_w0, float* g_b0,
+                          float* g_w1, float* g_b1, hipStream_t stream);
+// single-evaluation VJP pieces (csrc/sampler_bwd.hip, csrc/net_eval.hip)
+int launch_eval_du(const BArgs& b, const float* w0_rows, int n_rows, float* du, hipStream_t stream);   // du[b][k] = W0[A + k] . dL/dz_0[b]
+struct TimeBwdSampleArgs {
+  const float* t; const float* du; int du_stride;        // (B,) time inputs; dL/dtfeat = du[b][0 .. D)
+  const float* time_kernel; const float* tk0; const float* tb0; const float* tk1; const float* tb1;
+  float* scratch;                                        // (B, 4 D + D / 2): temb | h1 | dz1 | dz2 | 2 pi t gf
+  float* g_tk0; float* g_tb0; float* g_tk1; float* g_tb1; float* g_time_kernel;
+  long long B; int D, time_embed;
+};
+int launch_time_bwd_samples(const TimeBwdSampleArgs& a, hipStream_t stream);
 int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order second stage of the weight-gradient reduction
 
 // ---- backward, bf16-MFMA variant (csrc/sampler_bwd_bf16.hip) -------------------------------------------------

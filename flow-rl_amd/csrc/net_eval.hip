@@ -97,6 +97,126 @@ int launch_time_rows(const FrlDesc& d, const FrlParams& p, const float* t, const
   return FRL_OK;
 }
 
+// ---- per-sample time-branch backward (the single-evaluation VJP) ---------------------------------------------------------
+// dL/dtfeat[b] (the first D entries of du[b]) -> MLP_0 (mish, mish) and, for the Fourier embedding, its kernel.  Two stages
+// like the cond_embedding backward: a per-sample chain rule (64 threads per sample, double precision: O(D^2) per sample) that
+// leaves temb | h1 | dL/dz1 | dL/dz2 | 2 pi t gf in scratch, then one thread per gradient element adding the samples in index
+// order (bitwise reproducible).
+__device__ __forceinline__ void mish_grad_d(double x, double& h, double& d) {
+  const double sp = (x > 30.0) ? x : log1p(exp(x));
+  const double th = tanh(sp);
+  const double sg = 1.0 / (1.0 + exp(-x));
+  h = x * th;
+  d = th + x * (1.0 - th * th) * sg;
+}
+
+__global__ void __launch_bounds__(256) frl_time_bwd_sample_kernel(const TimeBwdSampleArgs a) {
+  extern __shared__ double shd[];     // [4 samples][4][D]: temb | h1 | dz2 | dz1
+  const int g = threadIdx.x >> 6, gt = threadIdx.x & 63;
+  const long long b = (long long)blockIdx.x * 4 + g;
+  const int D = a.D, half = D / 2;
+  double* temb = shd + (size_t)g * 4 * D;
+  double* h1 = temb + D;
+  double* dz2 = h1 + D;
+  double* dz1 = dz2 + D;
+  const bool valid = b < a.B;
+  const float tv = valid ? a.t[b] : 0.0f;
+  for (int d = gt; d < D; d += 64) {
+    const int dd = (d < half) ? d : d - half;
+    float arg;
+    if (a.time_embed == FRL_TEMB_POSITIONAL) {
+      const float lf = (float)log(10000.0) / (float)(half - 1);
+      arg = tv * (float)exp((double)((float)dd * -lf));
+    } else {
+      arg = (6.283185307179586f * tv) * a.time_kernel[dd];
+    }
+    temb[d] = (d < half) ? cos((double)arg) : sin((double)arg);
+  }
+  __syncthreads();
+  double a1[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};     // mish'(z1), mish'(z2) of this thread's features (D <= 128)
+  for (int d = gt, i = 0; d < D; d += 64, ++i) {
+    double z = a.tb0[d];
+    for (int k = 0; k < D; ++k) z += temb[k] * (double)a.tk0[(size_t)k * D + d];
+    double h, dh;
+    mish_grad_d(z, h, dh);
+    h1[d] = h; a1[i] = dh;
+  }
+  __syncthreads();
+  for (int d = gt, i = 0; d < D; d += 64, ++i) {
+    double z = a.tb1[d];
+    for (int k = 0; k < D; ++k) z += h1[k] * (double)a.tk1[(size_t)k * D + d];
+    double h, dh;
+    mish_grad_d(z, h, dh);
+    a2[i] = dh;
+    dz2[d] = valid ? (double)a.du[(size_t)b * a.du_stride + d] * dh : 0.0;
+  }
+  __syncthreads();
+  for (int d = gt, i = 0; d < D; d += 64, ++i) {
+    double s = 0.0;
+    for (int o = 0; o < D; ++o) s += (double)a.tk1[(size_t)d * D + o] * dz2[o];
+    dz1[d] = s * a1[i];
+  }
+  __syncthreads();
+  if (!valid) return;
+  float* sc = a.scratch + (size_t)b * (4 * D + half);
+  for (int d = gt; d < D; d += 64) {
+    sc[d] = (float)temb[d]; sc[D + d] = (float)h1[d]; sc[2 * D + d] = (float)dz1[d]; sc[3 * D + d] = (float)dz2[d];
+  }
+  if (a.time_embed == FRL_TEMB_FOURIER) {
+    for (int d = gt; d < half; d += 64) {
+      double gc = 0.0, gs = 0.0;          // dL/dtemb[d] (cos part), dL/dtemb[half + d] (sin part) = W_t0 rows . dz1
+      for (int o = 0; o < D; ++o) { gc += (double)a.tk0[(size_t)d * D + o] * dz1[o]; gs += (double)a.tk0[(size_t)(half + d) * D + o] * dz1[o]; }
+      const double gf = -temb[half + d] * gc + temb[d] * gs;      // f = 2 pi t w: d cos f = -sin f, d sin f = cos f
+      sc[4 * D + d] = (float)(6.283185307179586 * (double)tv * gf);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) frl_time_bwd_reduce_kernel(const TimeBwdSampleArgs a) {
+  const int D = a.D, half = D / 2, S = 4 * D + half;
+  const long long n0 = (long long)D * D, total = 2 * n0 + 2 * D + (a.time_embed == FRL_TEMB_FOURIER ? half : 0);
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int kind, i = 0, o;     // 0: dW0[i][o] = temb[i] dz1[o]   1: db0[o]   2: dW1[i][o] = h1[i] dz2[o]   3: db1[o]   4: d time kernel[o]
+  long long r = e;
+  if (r < n0) { kind = 0; i = (int)(r / D); o = (int)(r % D); }
+  else if ((r -= n0) < D) { kind = 1; o = (int)r; }
+  else if ((r -= D) < n0) { kind = 2; i = (int)(r / D); o = (int)(r % D); }
+  else if ((r -= n0) < D) { kind = 3; o = (int)r; }
+  else { kind = 4; o = (int)(r - D); }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (long long s = 0; s < a.B; ++s) {
+    const float* sc = a.scratch + (size_t)s * S;
+    double v;
+    if (kind == 0) v = (double)sc[i] * (double)sc[2 * D + o];
+    else if (kind == 1) v = sc[2 * D + o];
+    else if (kind == 2) v = (double)sc[D + i] * (double)sc[3 * D + o];
+    else if (kind == 3) v = sc[3 * D + o];
+    else v = sc[4 * D + o];
+    acc[s & 3] += v;
+  }
+  const float sum = (float)((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  if (kind == 0) a.g_tk0[(size_t)i * D + o] = sum;
+  else if (kind == 1) a.g_tb0[o] = sum;
+  else if (kind == 2) a.g_tk1[(size_t)i * D + o] = sum;
+  else if (kind == 3) a.g_tb1[o] = sum;
+  else a.g_time_kernel[o] = sum;
+}
+
+int launch_time_bwd_samples(const TimeBwdSampleArgs& a, hipStream_t stream) {
+  if (a.B <= 0 || a.time_embed == FRL_TEMB_NONE) return FRL_OK;
+  if (a.D > 128 || a.D < 4) { set_error("single-evaluation VJP: time_dim %d outside [4, 128]", a.D); return FRL_EUNSUPPORTED; }
+  const size_t lds = sizeof(double) * 4 * 4 * (size_t)a.D;
+  hipLaunchKernelGGL(frl_time_bwd_sample_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), lds, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("time bwd (samples) launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  const long long total = 2LL * a.D * a.D + 2 * a.D + (a.time_embed == FRL_TEMB_FOURIER ? a.D / 2 : 0);
+  hipLaunchKernelGGL(frl_time_bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("time bwd (reduce) launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
+
 // ---- forward process -----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 frl_add_noise_kernel(int kind, long long B, int A, const float* __restrict__ x0, const float* __restrict__ e, const void* __restrict__ tv,

@@ -237,6 +237,19 @@ frl_bwd_sweep_kernel(const BArgs b) {
       // ================= forward of step j, recomputed =====================================================
       sfor<RING - 1>([&](auto NI) { l0load(NI); });
       bias_init(P, s_tb + j * H);
+      if (a.state_bias != nullptr) {
+        // single-evaluation VJP (frl_net_eval_train): the time and condition rows of Dense_0 arrive as one accumulator-init
+        // row per chain (u[b] @ kernel_0[A:], frl_state_bias_kernel); the kernel itself contracts the x rows only
+        const float* zrow = a.state_bias + (valid ? state : 0) * H;
+        sfor<NG>([&](auto GI) {
+          constexpr int g = decltype(GI)::value;
+          sfor<NR>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            const f32x4 bv = *(const f32x4*)(zrow + g * GW + 4 * (G::rowr(r) + 4 * ls));
+            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] += bv[jj]; });
+          });
+        });
+      }
       sfor<N0>([&](auto NI) {
         constexpr int n = decltype(NI)::value;
         if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});
@@ -348,7 +361,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
           const int ai = G::rowr(r) + 4 * ls;
           const bool in = valid && ai < a.A;
           const float eps = O[r], xt = xs[r];
-          if (in) {
+          if (in && a.xt_hist != nullptr) {
             const long long o = ((long long)j * a.B + chain) * a.A + ai;
             a.xt_hist[o] = xt;
             a.eps_hist[o] = eps;
@@ -371,6 +384,8 @@ frl_bwd_sweep_kernel(const BArgs b) {
             float x0h = (xt - c1 * eps) / c0;
             if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
             xn = c2 * x0h + c3 * eps;
+          } else if (a.mode == MODE_EVAL) {
+            xn = eps;                                                 // one plain evaluation: the output itself
           } else {
             xn = xt + eps / c0;
             if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
@@ -418,7 +433,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
         sfor<NRX>([&](auto RI) {                           // the training forward kept eps_hist and the stash
           constexpr int r = decltype(RI)::value;
           const int ai = G::rowr(r) + 4 * ls;
-          O[r] = (valid && ai < a.A) ? b.eps_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+          O[r] = (valid && ai < a.A && b.eps_hist != nullptr) ? b.eps_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         });
       }
 
@@ -447,6 +462,8 @@ frl_bwd_sweep_kernel(const BArgs b) {
           const float g0 = c2 * gn * m;
           if (a.mode == MODE_CDDPM_DDPM) { g_e = -(c1 / c0) * g0; g_x = c3 * gn + g0 / c0; }
           else { g_e = -(c1 / c0) * g0 + c3 * gn; g_x = g0 / c0; }
+        } else if (a.mode == MODE_EVAL) {
+          g_e = gn; g_x = 0.0f;                                     // the cotangent of the evaluation's output, nothing direct
         } else {
           const float xn = xt + eps / c0;
           const float m = (!a.clip || (xn >= a.x_min && xn <= a.x_max)) ? 1.0f : 0.0f;
@@ -592,7 +609,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;       // 8 waves: 4 (X blocks 2 wm, 2 wm + 1) x 2 (G blocks 4 wn .. 4 wn + 3)
-  const int A = a.A, C = a.C, T = a.T, L = a.L;
+  const int A = a.A, C = b.dw_C, T = a.T, L = a.L;
   constexpr int NM = (KIND == 1) ? 2 : (KIND == 0 ? NM0 : 1), NN = (KIND == 1) ? 4 : 1;
   const int mb0 = (KIND == 1) ? 2 * wm : (KIND == 2 ? wave : 0);
   const int nb0 = (KIND == 1) ? 4 * wn : (KIND == 0 ? wave : 0);
@@ -629,7 +646,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
         float v = 0.0f;
         if (chain < a.B) {
           if (row < A) v = b.xt_hist[((long long)j * a.B + chain) * A + row];
-          else if (row < A + C) v = a.cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
+          else if (row < A + C) v = b.dw_cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
         }
         xv[k] = v;
       });
@@ -723,7 +740,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
         constexpr int r = decltype(RI)::value;
         const int in = 32 * (mb0 + m) + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int out = 32 * (nb0 + n) + li;
-        pk[(size_t)in * PCOL + out] = acc[m][n][r];
+        if (KIND != 0 || in < b.k0_rows) pk[(size_t)in * PCOL + out] = acc[m][n][r];    // NM0 blocks may exceed the slot's k0_rows
       });
     });
   });
@@ -740,7 +757,7 @@ __device__ __forceinline__ void dw_layer_f32(const BArgs& b, int lam, float* sme
 // partial sums combined as a tree: a fixed order, hence bitwise reproducible, and shorter rounding chains than one sum.
 __global__ void __launch_bounds__(256) frl_bwd_reduce_kernel(const BArgs b) {
   const KArgs& a = b.k;
-  const int A = a.A, C = a.C, T = a.T, L = a.L, Dp = b.Dp, H = 256;
+  const int A = a.A, C = b.dw_C, T = a.T, L = a.L, Dp = b.Dp, H = 256;
   const DwPart dp = dw_part_layout(L, T, b.k0_rows);
   const long long n0 = (long long)(A + Dp + C) * H, nh = (long long)(L - 1) * 65536, nl = (long long)H * A;
   const long long nb = (long long)(L - 1) * H + A, ntb = (long long)T * H;
@@ -789,7 +806,7 @@ __global__ void __launch_bounds__(256) frl_bwd_reduce_kernel(const BArgs b) {
 
 int launch_bwd_reduce(const BArgs& b, hipStream_t stream) {
   const KArgs& a = b.k;
-  const long long total = (long long)(a.A + b.Dp + a.C) * 256 + (long long)(a.L - 1) * 65536 + 256LL * a.A + (long long)(a.L - 1) * 256 + a.A + (long long)a.T * 256;
+  const long long total = (long long)(a.A + b.Dp + b.dw_C) * 256 + (long long)(a.L - 1) * 65536 + 256LL * a.A + (long long)(a.L - 1) * 256 + a.A + (long long)a.T * 256;
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(frl_bwd_reduce_kernel, dim3(grid), dim3(256), 0, stream, b);
   hipError_t e = hipGetLastError();
@@ -805,11 +822,50 @@ frl_bwd_dw_kernel(const BArgs b) {
   const long long U = n_wt * a.T;                         // tile-steps, step-major: u = j * n_wt + wt
   const long long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
   if (b.k0_rows <= 32) dw_layer_f32<0, 1>(b, 0, smem_dw, u0, u1, n_wt);
-  else dw_layer_f32<0, 5>(b, 0, smem_dw, u0, u1, n_wt);      // DACER / QVPO shapes: x (<= 24) | cond (<= 128) rows = up to 5 blocks
+  else if (b.k0_rows <= 160) dw_layer_f32<0, 5>(b, 0, smem_dw, u0, u1, n_wt);   // DACER / QVPO shapes: x (<= 24) | cond (<= 128) rows = up to 5 blocks
+  else dw_layer_f32<0, 7>(b, 0, smem_dw, u0, u1, n_wt);      // single-evaluation VJP: x | tfeat (64) | cfeat (128) = up to 7 blocks
   for (int lam = 1; lam < a.L; ++lam) dw_layer_f32<1>(b, lam, smem_dw, u0, u1, n_wt);
   dw_layer_f32<2>(b, a.L, smem_dw, u0, u1, n_wt);
 }
 
+// dL/du of the single-evaluation VJP: du[b][k] = sum_f W0[A + k][f] dL/dz_0[b][f] for the n_rows rows of Dense_0 that the
+// forward hoisted into the per-sample init row (u = [tfeat | cond]).  One workgroup per wave-tile (T = 1): the tile's
+// dL/dz_0 stash block goes through LDS transposed ([feature][33]), then 256 threads share the 32 x n_rows dot products.
+__global__ void __launch_bounds__(256) frl_eval_du_kernel(const BArgs b, const float* __restrict__ w0_rows, int n_rows, float* __restrict__ du) {
+  __shared__ float sG[256 * 33];
+  const KArgs& a = b.k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31;
+  const long long wt = blockIdx.x;
+  const float* src = b.gd + (size_t)wt * a.T * a.L * 8192;          // layer 0 of tile-step (wt, j = 0)
+  for (int q = 0; q < 16; ++q) {
+    const int row2 = wave + 4 * q;
+    const f32x2 v = *(const f32x2*)(src + ((size_t)row2 * 64 + lane) * 2);
+    sG[stash_feature(row2, 0, lane) * 33 + li] = v[0];
+    sG[stash_feature(row2, 1, lane) * 33 + li] = v[1];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 32 * n_rows; idx += 256) {
+    const int c = idx & 31, k = idx >> 5;
+    const long long chain = wt * 32 + c;
+    if (chain >= a.B) continue;
+    const float* wr = w0_rows + (size_t)k * 256;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int f = 0; f < 256; f += 4) {
+      s0 = fmaf(wr[f], sG[f * 33 + c], s0); s1 = fmaf(wr[f + 1], sG[(f + 1) * 33 + c], s1);
+      s2 = fmaf(wr[f + 2], sG[(f + 2) * 33 + c], s2); s3 = fmaf(wr[f + 3], sG[(f + 3) * 33 + c], s3);
+    }
+    du[chain * n_rows + k] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+int launch_eval_du(const BArgs& b, const float* w0_rows, int n_rows, float* du, hipStream_t stream) {
+  const long long n_wt = (b.k.B + 31) / 32;
+  if (n_wt <= 0 || n_rows <= 0) return FRL_OK;
+  hipLaunchKernelGGL(frl_eval_du_kernel, dim3((unsigned)n_wt), dim3(256), 0, stream, b, w0_rows, n_rows, du);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("eval du launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
+}
 #endif  // FRL_BWD_PHASE == 0
 
 // ---- launcher ---------------------------------------------------------------------------------------------------

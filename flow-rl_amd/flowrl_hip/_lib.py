@@ -81,6 +81,13 @@ class FrlEvalBufs(C.Structure):
     _fields_ = [("x", _fp), ("cond", _fp), ("t", _fp), ("out", _fp)]
 
 
+class FrlEvalBwdBufs(C.Structure):
+    _fields_ = [("x", _fp), ("cond", _fp), ("t", _fp), ("g_out", _fp), ("g_x", _fp),
+                ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)),
+                ("grad_tmlp_kernel", _fp * 2), ("grad_tmlp_bias", _fp * 2), ("grad_time_kernel", _fp),
+                ("grad_cond_kernel", _fp * 2), ("grad_cond_bias", _fp * 2)]
+
+
 FRL_NOISE_DDPM, FRL_NOISE_CDDPM_LINEAR, FRL_NOISE_CDDPM_COSINE, FRL_NOISE_FLOW = 0, 1, 2, 3
 FRL_MSE_WORKSPACE_BYTES = 2048
 
@@ -130,6 +137,9 @@ EXPORTS = {
     "frl_random_randint": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "frl_net_eval_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
     "frl_net_eval": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlEvalBufs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_net_eval_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
+    "frl_net_eval_train": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlEvalBufs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_net_eval_bwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlEvalBwdBufs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_add_noise": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
                                 C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frl_ddpm_onestep_update": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

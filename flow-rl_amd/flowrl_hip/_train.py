@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from . import random as _random
+from .module import LearnableFourierEmbedding
 from ._sampler import _f32c, _split_condition, _workspace, build_desc, build_params, check_param_shapes
 
 
@@ -55,6 +56,110 @@ def net_eval(network, params: Dict, x: torch.Tensor, t: torch.Tensor, condition:
         rc = lib.frl_net_eval(C.byref(desc), C.byref(fparams), C.byref(bufs), ws.data_ptr(), ws.numel(), stream)
     _lib.check(rc)
     return out.reshape(*lead, A)
+
+
+class EvalVjpContext:
+    """What :func:`net_eval_train` leaves for :func:`net_eval_vjp`: descriptor / parameter pointers, the inputs, and the
+    workspace holding the stash of the one evaluation."""
+    __slots__ = ("network", "params", "desc", "fparams", "keep", "ws", "x", "t", "cond2d", "B", "A", "lead")
+
+
+def net_eval_train(network, params: Dict, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, *,
+                   particles: Optional[int] = None):
+    """``model.apply({"params": p}, xt, t, condition, training=True)`` inside a loss that jax.grad differentiates
+    (ddpm.py:286-296, continuous_ddpm.py:234-243, cnf.py:155-165): frl_net_eval_train = the evaluation plus the stash
+    its backward reads.  Returns (out, ctx); pass ``ctx`` and dL/dout to :func:`net_eval_vjp`."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError("flowrl_hip runs on the GPU only; there is no CPU fallback")
+    device = x.device
+    A = x.shape[-1]
+    lead = tuple(x.shape[:-1])
+    n_states, parts, cond2d = _split_condition(x, condition, particles)
+    cond_dim = 0 if cond2d is None else cond2d.shape[-1]
+    check_param_shapes(network, params, A, cond_dim)
+    keep: list = []
+    desc = build_desc(network, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=1, n_states=n_states, particles=parts,
+                      x_dim=A, cond_dim=cond_dim, clip_sampler=False, x_min=None, x_max=None, want_history=False,
+                      tile_policy="auto")
+    fparams = build_params(network, params, device, keep)
+    B = n_states * parts
+    if t.numel() != B:
+        raise ValueError(f"t has {t.numel()} elements, expected one per sample ({B})")
+    tf = _f32c(t.reshape(B).to(torch.float32), device, "t")
+    xin = _f32c(x.reshape(B, A), device, "x")
+    out = torch.empty((B, A), dtype=torch.float32, device=device)
+    bufs = _lib.FrlEvalBufs()
+    bufs.x, bufs.t, bufs.out = xin.data_ptr(), tf.data_ptr(), out.data_ptr()
+    if cond2d is not None:
+        cond2d = _f32c(cond2d, device, "condition")
+        bufs.cond = cond2d.data_ptr()
+    need = lib.frl_net_eval_bwd_workspace_bytes(C.byref(desc))
+    stream = torch.cuda.current_stream(device).cuda_stream
+    if need == 0:
+        _lib.check(lib.frl_net_eval_train(C.byref(desc), C.byref(fparams), C.byref(bufs), None, 0, stream))
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "this configuration has no single-evaluation VJP kernel")
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)      # owned by the context: the stash must survive
+    with torch.cuda.device(device):
+        rc = lib.frl_net_eval_train(C.byref(desc), C.byref(fparams), C.byref(bufs), ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc)
+    ctx = EvalVjpContext()
+    ctx.network, ctx.params, ctx.desc, ctx.fparams, ctx.keep, ctx.ws = network, params, desc, fparams, keep, ws
+    ctx.x, ctx.t, ctx.cond2d, ctx.B, ctx.A, ctx.lead = xin, tf, cond2d, B, A, lead
+    return out.reshape(*lead, A), ctx
+
+
+def _grad_like(leaf: Dict):
+    gk = torch.empty_like(leaf["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
+    gb = torch.empty_like(leaf["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
+    return gk, gb
+
+
+def net_eval_vjp(ctx: EvalVjpContext, g_out: torch.Tensor, want_gx: bool = False):
+    """dL/dparams (Flax-layout tree, every leaf of the model) and optionally dL/dx of the evaluation ``ctx`` came from,
+    given dL/dout: frl_net_eval_bwd (backward sweep from the stash, weight-gradient GEMMs with a fixed-order reduce,
+    per-sample time branch and cond_embedding backward).  Deterministic."""
+    lib = _lib.load()
+    device = ctx.x.device
+    network, params, B, A = ctx.network, ctx.params, ctx.B, ctx.A
+    if g_out.numel() != B * A:
+        raise ValueError(f"g_out has {g_out.numel()} elements, expected {B * A}")
+    g_in = _f32c(g_out.reshape(B, A), device, "g_out")
+    bufs = _lib.FrlEvalBwdBufs()
+    bufs.x, bufs.t, bufs.g_out = ctx.x.data_ptr(), ctx.t.data_ptr(), g_in.data_ptr()
+    if ctx.cond2d is not None:
+        bufs.cond = ctx.cond2d.data_ptr()
+    g_x = torch.empty((B, A), dtype=torch.float32, device=device) if want_gx else None
+    if g_x is not None:
+        bufs.g_x = g_x.data_ptr()
+    pname = network.predictor_name
+    grads: Dict = {pname: {}}
+    for i in range(len(network.predictor.hidden_dims) + 1):
+        gk, gb = _grad_like(params[pname][f"Dense_{i}"])
+        grads[pname][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
+        bufs.grad_kernel[i], bufs.grad_bias[i] = gk.data_ptr(), gb.data_ptr()
+    te = network.time_embedding
+    if te is not None:
+        grads["MLP_0"] = {}
+        for i in range(2):
+            gk, gb = _grad_like(params["MLP_0"][f"Dense_{i}"])
+            grads["MLP_0"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
+            bufs.grad_tmlp_kernel[i], bufs.grad_tmlp_bias[i] = gk.data_ptr(), gb.data_ptr()
+        if isinstance(te, LearnableFourierEmbedding):
+            gw = torch.empty_like(params["time_embedding"]["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
+            grads["time_embedding"] = {"kernel": gw}
+            bufs.grad_time_kernel = gw.data_ptr()
+    if network.cond_embedding is not None:
+        grads["cond_embedding"] = {}
+        for i in range(2):
+            gk, gb = _grad_like(params["cond_embedding"][f"Dense_{i}"])
+            grads["cond_embedding"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
+            bufs.grad_cond_kernel[i], bufs.grad_cond_bias[i] = gk.data_ptr(), gb.data_ptr()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        rc = lib.frl_net_eval_bwd(C.byref(ctx.desc), C.byref(ctx.fparams), C.byref(bufs), ctx.ws.data_ptr(), ctx.ws.numel(), stream)
+    _lib.check(rc)
+    return grads, (g_x.reshape(*ctx.lead, A) if g_x is not None else None)
 
 
 def add_noise(kind: int, x0: torch.Tensor, e: torch.Tensor, t: torch.Tensor, *, alpha_hats: Optional[torch.Tensor] = None,

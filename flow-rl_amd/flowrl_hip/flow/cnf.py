@@ -66,10 +66,17 @@ class ContinuousNormalizingFlow:
 
     # ---- training-side half ---------------------------------------------------------------------
     def __call__(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
-                 params: Optional[Dict] = None, *, particles: Optional[int] = None) -> torch.Tensor:
+                 params: Optional[Dict] = None, *, particles: Optional[int] = None, keep_for_vjp: bool = False):
         """``self(xt, t, condition)`` with a per-sample time in [0, 1] (frl_net_eval)."""
         p = params if (training and params is not None) else self.params
+        if keep_for_vjp:      # (out, ctx) for eval_vjp: the evaluation under jax.grad
+            return _train.net_eval_train(self.network, p, x, t, condition, particles=particles)
         return _train.net_eval(self.network, p, x, t, condition, particles=particles)
+
+    @staticmethod
+    def eval_vjp(ctx, g_out: torch.Tensor, want_gx: bool = False):
+        """dL/dparams (every leaf) [and dL/dx] of a ``self(x, t, condition, True, params, keep_for_vjp=True)`` call."""
+        return _train.net_eval_vjp(ctx, g_out, want_gx)
 
     def step2t(self, step):
         """cnf.py:80-83."""
@@ -98,10 +105,19 @@ class ContinuousNormalizingFlow:
 
 
 def flow_matching_loss(rng, model: ContinuousNormalizingFlow, x0: torch.Tensor, x1: torch.Tensor,
-                       condition: Optional[torch.Tensor] = None, params: Optional[Dict] = None, *, rng_impl: Optional[str] = None):
+                       condition: Optional[torch.Tensor] = None, params: Optional[Dict] = None, *, rng_impl: Optional[str] = None,
+                       want_grads: bool = False):
     """The loss of jit_update_flow_matching (cnf.py:145-170): rng, xt, t, vel = model.linear_interpolation(rng, x0, x1);
-    vel_pred = model.apply(params, xt, t, condition); loss = ((vel_pred - vel) ** 2).mean().  Returns (rng, loss, aux)."""
+    vel_pred = model.apply(params, xt, t, condition); loss = ((vel_pred - vel) ** 2).mean().  Returns (rng, loss, aux);
+    ``want_grads`` adds aux["grads"] = dloss / dparams."""
     rng, xt, t, vel = model.linear_interpolation(rng, x0, x1, rng_impl=rng_impl)
-    vel_pred = model(xt, t, condition, True, params if params is not None else model.params)
+    p = params if params is not None else model.params
+    if want_grads:
+        vel_pred, ctx = model(xt, t, condition, True, p, keep_for_vjp=True)
+    else:
+        vel_pred = model(xt, t, condition, True, p)
     loss, g = _train.mse_loss(vel_pred, vel, want_grad=True)
-    return rng, loss, {"xt": xt, "t": t, "vel": vel, "vel_pred": vel_pred, "g_vel_pred": g}
+    aux = {"xt": xt, "t": t, "vel": vel, "vel_pred": vel_pred, "g_vel_pred": g}
+    if want_grads:
+        aux["grads"] = model.eval_vjp(ctx, g)[0]
+    return rng, loss, aux

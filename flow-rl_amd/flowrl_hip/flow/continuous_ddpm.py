@@ -112,10 +112,17 @@ class ContinuousDDPM:
 
     # ---- training-side half ---------------------------------------------------------------------
     def __call__(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
-                 params: Optional[Dict] = None, *, particles: Optional[int] = None) -> torch.Tensor:
+                 params: Optional[Dict] = None, *, particles: Optional[int] = None, keep_for_vjp: bool = False):
         """``self(xt, t, condition)`` with a per-sample continuous time (frl_net_eval)."""
         p = params if (training and params is not None) else self.params
+        if keep_for_vjp:      # (out, ctx) for eval_vjp: the evaluation under jax.grad
+            return _train.net_eval_train(self.network, p, x, t, condition, particles=particles)
         return _train.net_eval(self.network, p, x, t, condition, particles=particles)
+
+    @staticmethod
+    def eval_vjp(ctx, g_out: torch.Tensor, want_gx: bool = False):
+        """dL/dparams (every leaf) [and dL/dx] of a ``self(x, t, condition, True, params, keep_for_vjp=True)`` call."""
+        return _train.net_eval_vjp(ctx, g_out, want_gx)
 
     def _noise_kind(self):
         fn = self.noise_schedule_func
@@ -164,9 +171,17 @@ class ContinuousDDPM:
 
 
 def continuous_ddpm_loss(rng, model: ContinuousDDPM, x0: torch.Tensor, condition: Optional[torch.Tensor] = None,
-                         params: Optional[Dict] = None, *, rng_impl: Optional[str] = None):
-    """The loss of jit_update_continuous_ddpm (continuous_ddpm.py:226-245).  Returns (rng, loss, aux) as ddpm_loss does."""
+                         params: Optional[Dict] = None, *, rng_impl: Optional[str] = None, want_grads: bool = False):
+    """The loss of jit_update_continuous_ddpm (continuous_ddpm.py:226-245).  Returns (rng, loss, aux) as ddpm_loss does
+    (``want_grads``: aux["grads"] = dloss / dparams)."""
     rng, xt, t, eps = model.add_noise(rng, x0, rng_impl=rng_impl)
-    eps_pred = model(xt, t, condition, True, params if params is not None else model.params)
+    p = params if params is not None else model.params
+    if want_grads:
+        eps_pred, ctx = model(xt, t, condition, True, p, keep_for_vjp=True)
+    else:
+        eps_pred = model(xt, t, condition, True, p)
     loss, g = _train.mse_loss(eps_pred, eps, want_grad=True)
-    return rng, loss, {"xt": xt, "t": t, "eps": eps, "eps_pred": eps_pred, "g_eps_pred": g}
+    aux = {"xt": xt, "t": t, "eps": eps, "eps_pred": eps_pred, "g_eps_pred": g}
+    if want_grads:
+        aux["grads"] = model.eval_vjp(ctx, g)[0]
+    return rng, loss, aux

@@ -105,11 +105,18 @@ class DDPM:
 
     # ---- training-side half ---------------------------------------------------------------------
     def __call__(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
-                 params: Optional[Dict] = None, *, particles: Optional[int] = None) -> torch.Tensor:
+                 params: Optional[Dict] = None, *, particles: Optional[int] = None, keep_for_vjp: bool = False):
         """``self(xt, t, condition)`` (module/model.py:62-73 -> DDPMBackbone, ddpm.py:83-95) with a per-sample time input:
         one fused MFMA evaluation per sample (frl_net_eval).  ``t``: integer steps, (..., 1) or (...)."""
         p = params if (training and params is not None) else self.params
+        if keep_for_vjp:      # (out, ctx) for eval_vjp: the evaluation under jax.grad
+            return _train.net_eval_train(self.network, p, x, t, condition, particles=particles)
         return _train.net_eval(self.network, p, x, t, condition, particles=particles)
+
+    @staticmethod
+    def eval_vjp(ctx, g_out: torch.Tensor, want_gx: bool = False):
+        """dL/dparams (every leaf) [and dL/dx] of a ``self(x, t, condition, True, params, keep_for_vjp=True)`` call."""
+        return _train.net_eval_vjp(ctx, g_out, want_gx)
 
     def add_noise(self, rng, x0: torch.Tensor, *, rng_impl: Optional[str] = None):
         """DDPM.add_noise (ddpm.py:164-171): rng, t_rng, noise_rng = split(rng, 3); t = randint(t_rng, (..., 1), 1, steps + 1);
@@ -172,11 +179,19 @@ class DDPM:
 
 
 def ddpm_loss(rng, model: DDPM, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, params: Optional[Dict] = None, *,
-              rng_impl: Optional[str] = None):
+              rng_impl: Optional[str] = None, want_grads: bool = False):
     """The loss of jit_update_ddpm (ddpm.py:280-304): rng, xt, t, eps = model.add_noise(rng, x0);
     eps_pred = model.apply(params, xt, t, condition); loss = ((eps_pred - eps) ** 2).mean().  Returns (rng, loss, aux) with
-    aux = {xt, t, eps, eps_pred, g_eps_pred = dloss / deps_pred}; the optimizer step (optax, model.py:78-86) stays with the caller."""
+    aux = {xt, t, eps, eps_pred, g_eps_pred = dloss / deps_pred}; ``want_grads`` adds aux["grads"] = dloss / dparams (what
+    model.apply_gradient's jax.grad, module/model.py:78-86, hands optax).  The optimizer step stays with the caller."""
     rng, xt, t, eps = model.add_noise(rng, x0, rng_impl=rng_impl)
-    eps_pred = model(xt, t, condition, True, params if params is not None else model.params)
+    p = params if params is not None else model.params
+    if want_grads:
+        eps_pred, ctx = model(xt, t, condition, True, p, keep_for_vjp=True)
+    else:
+        eps_pred = model(xt, t, condition, True, p)
     loss, g = _train.mse_loss(eps_pred, eps, want_grad=True)
-    return rng, loss, {"xt": xt, "t": t, "eps": eps, "eps_pred": eps_pred, "g_eps_pred": g}
+    aux = {"xt": xt, "t": t, "eps": eps, "eps_pred": eps_pred, "g_eps_pred": g}
+    if want_grads:
+        aux["grads"] = model.eval_vjp(ctx, g)[0]
+    return rng, loss, aux

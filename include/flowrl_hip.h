@@ -347,6 +347,33 @@ size_t frl_net_eval_workspace_bytes(const FrlDesc* desc);
 int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* workspace, size_t workspace_bytes,
                  void* hip_stream);
 
+/* The same evaluation under jax.grad — `model.apply({"params": p}, xt, t, condition, training=True)` inside the loss
+ * functions of jit_update_ddpm / jit_update_continuous_ddpm / jit_update_flow_matching (ddpm.py:286-296,
+ * continuous_ddpm.py:234-243, cnf.py:155-165) and of every agent that adds its own epsilon / velocity loss on top of
+ * add_noise (dql.py:88-92, dac.py:113, qvpo.py:140, sdac.py:91, ...): frl_net_eval_train is frl_net_eval that also keeps
+ * act(z) / act'(z) of every layer in the workspace; frl_net_eval_bwd then takes dL/d out and writes dL/d of EVERY
+ * parameter leaf (predictor, MLP_0, time_embedding, cond_embedding) and optionally dL/dx.  f32, 256-wide predictor,
+ * mish / silu / relu, x_dim <= 24, time_dim + cond_dim <= 192 (DACER: 64 + 128), no LayerNorm; deterministic. */
+typedef struct FrlEvalBwdBufs {
+  const float* x;     /* (B, A)   as the forward call */
+  const float* cond;  /* (n_states, C | cond_in_dim) */
+  const float* t;     /* (B,) */
+  const float* g_out; /* (B, A) cotangent of the evaluation's output */
+  float* g_x;         /* (B, A) or NULL: dL/dx */
+  float* grad_kernel[FRL_MAX_HIDDEN + 1]; /* dL/d Dense_i kernel, ALL rows of Dense_0 (x | time | cond); OVERWRITTEN */
+  float* grad_bias[FRL_MAX_HIDDEN + 1];   /* dL/d Dense_i bias, i = 0..L */
+  float* grad_tmlp_kernel[2];             /* dL/d MLP_0/Dense_{0,1} (time_embed != FRL_TEMB_NONE) */
+  float* grad_tmlp_bias[2];
+  float* grad_time_kernel;                /* dL/d time_embedding/kernel (FRL_TEMB_FOURIER) */
+  float* grad_cond_kernel[2];             /* dL/d cond_embedding/Dense_{0,1} (desc.cond_embed) */
+  float* grad_cond_bias[2];
+} FrlEvalBwdBufs;
+size_t frl_net_eval_bwd_workspace_bytes(const FrlDesc* desc);
+int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* bwd_workspace, size_t workspace_bytes,
+                       void* hip_stream);
+int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEvalBwdBufs* bufs, void* bwd_workspace, size_t workspace_bytes,
+                     void* hip_stream);
+
 /* Forward process, elementwise over (B, A):
  *   FRL_NOISE_DDPM          xt = sqrt(alpha_hats[t]) x0 + sqrt(1 - alpha_hats[t]) eps, t (B,) int32   ddpm.py:164-171
  *   FRL_NOISE_CDDPM_LINEAR  alpha, sigma = linear_noise_schedule(t, beta0 = p0, beta1 = p1)            continuous_ddpm.py:19-24,107-115

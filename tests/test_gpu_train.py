@@ -177,3 +177,121 @@ def test_losses():
         l_ref, g_ref = orc.mse(pred.cpu().numpy().astype(np.float64), target.cpu().numpy().astype(np.float64))
         assert abs(float(loss) - l_ref) <= 1e-6 * max(1.0, abs(l_ref)), case.name
         assert np.abs(g.cpu().numpy() - g_ref).max() <= 1e-6 * np.abs(g_ref).max(), case.name
+
+
+# ---- the evaluation under jax.grad: frl_net_eval_train + frl_net_eval_bwd ------------------------------------------------
+EVAL_VJP_CASES = [
+    H.Case("evjp-dql", "ddpm", A=3, S=11, T=5, B=300, seed=60),
+    H.Case("evjp-ragged-nocond", "ddpm", A=2, S=0, T=20, B=33, hidden=(256,), act="relu", seed=61),
+    H.Case("evjp-cddpm-fourier", "cddpm", A=6, S=17, T=20, B=70, temb="learnable_fourier", schedule="cosine", act="silu", seed=62),
+    H.Case("evjp-cnf-raw-t", "cnf", A=8, S=39, T=10, B=100, hidden=(256, 256), temb=None, clip=False, seed=63),
+    H.Case("evjp-dacer-embed-particles", "cddpm", A=17, S=376, T=20, B=6 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
+           cond_embed=True, seed=64),
+    H.Case("evjp-wide-cond", "ddpm", A=17, S=128, T=5, B=64, seed=65),
+    H.Case("evjp-multi-tile", "ddpm", A=3, S=11, T=5, B=20000, seed=66),
+]
+
+
+def _flatten(tree, prefix=""):
+    out = {}
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            out.update(_flatten(v, prefix + k + "/"))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+@pytest.mark.parametrize("case", EVAL_VJP_CASES, ids=lambda c: c.name)
+def test_net_eval_vjp(case):
+    """dL/d(every parameter leaf) and dL/dx of ONE per-sample-time evaluation against the float64 manual-backprop oracle
+    (oracle/flowrl_oracle_vjp.py backbone_fwd / backbone_bwd).  Bars as the chain VJP's: per leaf max 1e-5, rms 2e-6 of the
+    leaf's largest entry."""
+    import torch
+    import flowrl_oracle_vjp as ov
+    params, x, cond, _ = H.make_inputs(case)
+    rng = np.random.default_rng(150 + case.seed)
+    t = _t_for(case, rng, case.B)
+    g = rng.standard_normal((case.B, case.A)).astype(np.float32)
+    p64 = orc.cast_tree(params, np.float64)
+    cd = None if cond is None else np.repeat(cond, case.particles, axis=0).astype(np.float64)
+    out_ref, cache = ov.backbone_fwd(case.spec, p64, x.astype(np.float64), t.astype(np.float64), cd)
+    gref: dict = {}
+    gx_ref = ov.backbone_bwd(case.spec, p64, cache, g.astype(np.float64), gref)
+    model = H.product_model(case, params)
+    parts = case.particles if case.particles > 1 else None
+    c = None if cond is None else torch.from_numpy(cond).cuda()
+    out, ctx = model(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), c, True, model.params, particles=parts, keep_for_vjp=True)
+    grads, gx = model.eval_vjp(ctx, torch.from_numpy(g).cuda(), want_gx=True)
+    grads2, _ = model.eval_vjp(ctx, torch.from_numpy(g).cuda())
+    torch.cuda.synchronize()
+    assert H.rel_err(out.cpu().numpy(), out_ref) <= 1e-5
+    got = {k: v.cpu().numpy() for k, v in _flatten(grads).items()}
+    ref = _flatten(gref)
+    assert set(got) == set(ref), (sorted(got), sorted(ref))
+    for k, v in _flatten(grads2).items():      # fixed-order reduce: a second backward from the same stash is bit-identical
+        assert np.array_equal(v.cpu().numpy(), got[k]), k
+    got["dL/dx"], ref["dL/dx"] = gx.cpu().numpy(), gx_ref
+    worst = []
+    for k in sorted(ref):
+        r = np.asarray(ref[k], np.float64)
+        assert got[k].shape == r.shape, k
+        d = got[k].astype(np.float64) - r
+        scale = max(np.abs(r).max(), 1e-30)
+        worst.append((np.abs(d).max() / scale, np.sqrt(np.mean(d * d)) / scale, k))
+    print(f"{case.name}: worst leaf max-err {max(worst)[0]:.2e} ({max(worst)[2]})")
+    for m, r, k in worst:
+        assert m <= 1e-5 and r <= 2e-6, f"{case.name}: {k} max {m:.2e} rms {r:.2e}"
+
+
+def test_loss_grads():
+    """jit_update_ddpm / continuous_ddpm / flow_matching with want_grads: aux["grads"] = d loss / d params, against the
+    oracle's backward of the same evaluation with the oracle's own MSE cotangent."""
+    import torch
+    import flowrl_oracle_vjp as ov
+    from flowrl_hip.flow.cnf import flow_matching_loss
+    from flowrl_hip.flow.continuous_ddpm import continuous_ddpm_loss
+    from flowrl_hip.flow.ddpm import ddpm_loss
+    key = tf.prng_key(6)
+    kt = torch.from_numpy(key).cuda()
+    rng = np.random.default_rng(13)
+    for case, fn in ((H.Case("lg-ddpm", "ddpm", A=3, S=11, T=5, B=256, seed=71), ddpm_loss),
+                     (H.Case("lg-cddpm", "cddpm", A=6, S=17, T=20, B=256, temb="learnable_fourier", schedule="cosine", seed=72), continuous_ddpm_loss),
+                     (H.Case("lg-fm", "cnf", A=8, S=39, T=10, B=256, temb=None, clip=False, hidden=(256, 256), seed=73), flow_matching_loss)):
+        params, xa, cond, _ = H.make_inputs(case)
+        model = H.product_model(case, params)
+        c = torch.from_numpy(cond).cuda()
+        if case.kind == "cnf":
+            xb = rng.standard_normal(xa.shape).astype(np.float32)
+            _, loss, aux = fn(kt, model, torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda(), c, want_grads=True)
+            target = aux["vel"]
+        else:
+            _, loss, aux = fn(kt, model, torch.from_numpy(xa).cuda(), c, want_grads=True)
+            target = aux["eps"]
+        torch.cuda.synchronize()
+        xt, t = aux["xt"].cpu().numpy().astype(np.float64), aux["t"].cpu().numpy().astype(np.float64)
+        p64 = orc.cast_tree(params, np.float64)
+        pred_ref, cache = ov.backbone_fwd(case.spec, p64, xt, t, cond.astype(np.float64))
+        l_ref, g_ref = orc.mse(pred_ref, target.cpu().numpy().astype(np.float64))
+        gref: dict = {}
+        ov.backbone_bwd(case.spec, p64, cache, g_ref, gref)
+        assert abs(float(loss) - l_ref) <= 1e-5 * max(1.0, abs(l_ref)), case.name
+        got, ref = _flatten(aux["grads"]), _flatten(gref)
+        assert set(got) == set(ref)
+        for k in ref:
+            r = np.asarray(ref[k], np.float64)
+            d = got[k].cpu().numpy().astype(np.float64) - r
+            assert np.abs(d).max() <= 2e-5 * max(np.abs(r).max(), 1e-30), (case.name, k, np.abs(d).max() / np.abs(r).max())
+
+
+def test_net_eval_vjp_refusals():
+    """Loud refusals: LayerNorm and non-256 widths have no backward kernel; a missing gradient buffer is FRL_EINVAL."""
+    import torch
+    from flowrl_hip import _lib
+    for case in (H.Case("evjp-ln", "ddpm", A=3, S=11, T=5, B=64, ln=True, seed=80),
+                 H.Case("evjp-512", "cnf", A=8, S=39, T=10, B=64, hidden=(512, 512), temb=None, clip=False, seed=81)):
+        params, x, cond, _ = H.make_inputs(case)
+        model = H.product_model(case, params)
+        t = _t_for(case, np.random.default_rng(1), case.B)
+        with pytest.raises(_lib.FlowRLHipUnsupported):
+            model(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(cond).cuda(), True, model.params, keep_for_vjp=True)
