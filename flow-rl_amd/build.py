@@ -29,6 +29,7 @@ SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []),
            ("sampler_bwd_bf16.hip", "sampler_bwd_bf16", ["-fno-slp-vectorize"])] + \
           [("sampler_bwd.hip", f"sampler_bwd_p{p}", [f"-DFRL_BWD_PHASE={p}"]) for p in range(3)] + \
           [("sampler_rs.hip", f"sampler_rs_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(7)] + \
+          [("sampler_res.hip", f"sampler_res_act{a}", [f"-DFRL_RES_ACT={a}"]) for a in range(6)] + \
           [("sampler_lat.hip", f"sampler_lat_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(7)]   # 6 = identity: the post-activation-LayerNorm units
 HEADERS = [CSRC / "frl_internal.h", CSRC / "frl_device.h", CSRC / "frl_bf16.h", CSRC / "frl_rng.h", ROOT / "include" / "flowrl_hip.h"]
 FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++17", "-Wno-unused-value",

@@ -89,6 +89,42 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
   }
 }
 
+// residual backbones (ResidualMLP / Simba): the throughput build of csrc/sampler_res.hip for every batch size
+static int launch_res_network(const KArgs& a, const ResArgs& ra, int act, hipStream_t stream) {
+  switch (act) {
+    case FRL_ACT_MISH: return launch_sampler_res_act<FRL_ACT_MISH>(a, ra, stream);
+    case FRL_ACT_SILU: return launch_sampler_res_act<FRL_ACT_SILU>(a, ra, stream);
+    case FRL_ACT_RELU: return launch_sampler_res_act<FRL_ACT_RELU>(a, ra, stream);
+    case FRL_ACT_GELU_TANH: return launch_sampler_res_act<FRL_ACT_GELU_TANH>(a, ra, stream);
+    case FRL_ACT_TANH: return launch_sampler_res_act<FRL_ACT_TANH>(a, ra, stream);
+    default: return launch_sampler_res_act<FRL_ACT_ELU>(a, ra, stream);
+  }
+}
+
+static int fill_res_args(const FrlDesc* d, const FrlParams* p, ResArgs& ra) {
+  memset(&ra, 0, sizeof(ra));
+  ra.n_blocks = d->n_hidden;
+  const bool simba = d->backbone == FRL_BACKBONE_SIMBA;
+  ra.ln = (simba || d->layer_norm) ? 1 : 0;
+  ra.final_ln = simba ? 1 : 0;
+  ra.final_act = simba ? 0 : 1;
+  for (int i = 0; i < d->n_hidden; ++i) {
+    for (int k = 0; k < 2; ++k)
+      if (p->res_kernel[i][k] == nullptr || p->res_bias[i][k] == nullptr) { set_error("params.res_kernel/res_bias[%d][%d] is NULL", i, k); return FRL_EINVAL; }
+    ra.w1[i] = p->res_kernel[i][0]; ra.b1[i] = p->res_bias[i][0];
+    ra.w2[i] = p->res_kernel[i][1]; ra.b2[i] = p->res_bias[i][1];
+    if (ra.ln) {
+      if (p->res_ln_scale[i] == nullptr || p->res_ln_bias[i] == nullptr) { set_error("params.res_ln_scale/res_ln_bias[%d] is NULL", i); return FRL_EINVAL; }
+      ra.ln_scale[i] = p->res_ln_scale[i]; ra.ln_bias[i] = p->res_ln_bias[i];
+    }
+  }
+  if (simba) {
+    if (p->final_ln_scale == nullptr || p->final_ln_bias == nullptr) { set_error("params.final_ln_scale/final_ln_bias is NULL (Simba)"); return FRL_EINVAL; }
+    ra.fln_scale = p->final_ln_scale; ra.fln_bias = p->final_ln_bias;
+  }
+  return FRL_OK;
+}
+
 static int validate_desc(const FrlDesc* d) {
   if (d == nullptr) { set_error("desc is NULL"); return FRL_EINVAL; }
   if (d->abi_version != FRL_ABI_VERSION) { set_error("desc.abi_version %d != library %d", d->abi_version, FRL_ABI_VERSION); return FRL_EINVAL; }
@@ -130,7 +166,20 @@ static int validate_desc(const FrlDesc* d) {
     if (d->cond_dim != COND_EMBED_DIM) { set_error("cond_embed: cond_dim must be %d (MLP(128,128)), got %d", COND_EMBED_DIM, d->cond_dim); return FRL_EUNSUPPORTED; }
     if (d->cond_in_dim < 1) { set_error("cond_embed: cond_in_dim %d invalid", d->cond_in_dim); return FRL_EINVAL; }
   }
+  if (d->backbone < FRL_BACKBONE_MLP || d->backbone > FRL_BACKBONE_SIMBA) { set_error("backbone %d invalid", d->backbone); return FRL_EINVAL; }
   // --- what this build has kernels for ---
+  if (d->backbone != FRL_BACKBONE_MLP) {
+    // csrc/sampler_res.hip: 256-wide blocks, expansion 4, f32 throughput build, forward
+    if (d->dtype != FRL_DTYPE_F32) { set_error("residual backbones: f32 kernel only"); return FRL_EUNSUPPORTED; }
+    if (d->res_multiplier != 4) { set_error("residual backbones: multiplier %d (4 is the only value built)", d->res_multiplier); return FRL_EUNSUPPORTED; }
+    for (int l = 0; l < d->n_hidden; ++l)
+      if (d->hidden[l] != 256) { set_error("residual backbones: hidden widths must all be 256 (hidden[%d] = %d)", l, d->hidden[l]); return FRL_EUNSUPPORTED; }
+    if (d->layer_norm == FRL_LN_POST_ACT) { set_error("residual backbones: layer_norm is 0 or FRL_LN_PRE_ACT (ResidualLinear normalises its input)"); return FRL_EINVAL; }
+    if (d->x_dim > 24) { set_error("residual backbones: x_dim %d > 24", d->x_dim); return FRL_EUNSUPPORTED; }
+    if (d->tile_policy != FRL_TILE_AUTO && d->tile_policy != FRL_TILE_THROUGHPUT) { set_error("residual backbones: no latency build (tile_policy %d)", d->tile_policy); return FRL_EUNSUPPORTED; }
+    if (res_lds_bytes((d->solver == FRL_SOLVER_DPM2 ? 2 : 1) * d->steps, d->n_hidden) > 160 * 1024) { set_error("residual backbones: %d steps x %d blocks exceed the LDS tables", d->steps, d->n_hidden); return FRL_EUNSUPPORTED; }
+    return FRL_OK;
+  }
   if (d->dtype == FRL_DTYPE_BF16) {
     // bf16 MFMA variant (csrc/sampler_bf16.hip): 256-wide predictor, bf16 operands / f32 accumulate / f32 chain state
     for (int l = 0; l < d->n_hidden; ++l)
@@ -193,6 +242,16 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
   const int A = desc->x_dim, C = desc->cond_dim;
   const int Dp = desc->time_embed == FRL_TEMB_NONE ? 1 : desc->time_dim;
   double macs = (double)(A + Dp + C) * desc->hidden[0];
+  if (desc->backbone != FRL_BACKBONE_MLP) {     // Dense_0, per block H x 4H + 4H x H, Dense_1
+    const double H = desc->hidden[0], blk = 2.0 * H * desc->res_multiplier * H;
+    const double cf = desc->cond_embed ? 2.0 * (double)desc->n_states * ((double)desc->cond_in_dim * COND_EMBED_DIM + (double)COND_EMBED_DIM * COND_EMBED_DIM) : 0.0;
+    if (executed != nullptr) {
+      Plan pl;
+      plan_from_desc(*desc, pl);
+      *executed = 2.0 * B * T * ((double)pl.XR * H + desc->n_hidden * blk + H * LAST_PAD) + cf + 2.0 * (double)desc->n_states * C * H;
+    }
+    return 2.0 * B * T * (macs + desc->n_hidden * blk + H * A) + cf;
+  }
   const double cond_flops = desc->cond_embed ? 2.0 * (double)desc->n_states * ((double)desc->cond_in_dim * COND_EMBED_DIM + (double)COND_EMBED_DIM * COND_EMBED_DIM) : 0.0;
   for (int l = 1; l < desc->n_hidden; ++l) macs += (double)desc->hidden[l - 1] * desc->hidden[l];
   macs += (double)desc->hidden[desc->n_hidden - 1] * A;
@@ -226,7 +285,7 @@ static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, co
   plan_from_desc(*desc, pl, allow_hoist);
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
-  for (int l = 0; l <= desc->n_hidden; ++l)
+  for (int l = 0; l <= pl.L; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
   if (desc->time_embed != FRL_TEMB_NONE) {
     for (int k = 0; k < 2; ++k)
@@ -252,7 +311,7 @@ static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, co
   pa.kind = desc->kind;
   pa.time_embed = desc->time_embed;
   rc = launch_prepare(pa, (hipStream_t)hip_stream);
-  if (rc == FRL_OK && desc->layer_norm) {
+  if (rc == FRL_OK && desc->layer_norm && desc->backbone == FRL_BACKBONE_MLP) {
     // LayerNorm scale | bias rows of every hidden layer, gathered into one [L][2][H] image the kernel stages in LDS
     float* ln = (float*)workspace + pl.off_ln;
     for (int l = 0; l < pl.L && rc == FRL_OK; ++l) {
@@ -297,11 +356,16 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   if (rng && bufs->rng_key == nullptr) { set_error("desc.rng_impl = %d but bufs.rng_key is NULL", desc->rng_impl); return FRL_EINVAL; }
   if (needs_noise && !rng && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step (or set desc.rng_impl and bufs.rng_key)"); return FRL_EINVAL; }
   if (desc->want_history && (bufs->xt_hist == nullptr || bufs->eps_hist == nullptr)) { set_error("want_history set but xt_hist / eps_hist is NULL"); return FRL_EINVAL; }
-  for (int l = 1; l < desc->n_hidden; ++l)
+  for (int l = 1; l < pl.L; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
   if (desc->cond_embed)
     for (int k = 0; k < 2; ++k)
       if (params->cond_kernel[k] == nullptr || params->cond_bias[k] == nullptr) { set_error("params.cond_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
+  ResArgs ra;
+  if (desc->backbone != FRL_BACKBONE_MLP) {
+    rc = fill_res_args(desc, params, ra);
+    if (rc != FRL_OK) return rc;
+  }
 
   const float* ws = (const float*)workspace;
   KArgs a;
@@ -339,10 +403,10 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   a.x0 = bufs->x0;
   a.xt_hist = desc->want_history ? bufs->xt_hist : nullptr;
   a.eps_hist = desc->want_history ? bufs->eps_hist : nullptr;
-  for (int l = 1; l < desc->n_hidden; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
+  for (int l = 1; l < pl.L; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
-  a.ws_ln = desc->layer_norm ? ws + pl.off_ln : nullptr;
+  a.ws_ln = (desc->layer_norm && desc->backbone == FRL_BACKBONE_MLP) ? ws + pl.off_ln : nullptr;
   a.ln_post_act = desc->layer_norm == FRL_LN_POST_ACT ? 1 + desc->act : 0;
   a.B = pl.B; a.particles = desc->particles; a.A = pl.A; a.C = pl.C; a.T = pl.T; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.NE = pl.NE; a.AO = pl.AO;
@@ -355,7 +419,8 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
     a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
     return launch_sampler_bf16(*desc, a, (hipStream_t)hip_stream);
   }
-  a.wl_raw = params->kernel[desc->n_hidden];
+  a.wl_raw = params->kernel[pl.L];
+  if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, (hipStream_t)hip_stream);
   return launch_f32_network(a, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
 }
 
@@ -396,6 +461,7 @@ static int validate_bwd(const FrlDesc* d) {
   plan_from_desc(*d, pl, false);       // the VJP never hoists the condition rows: they are contracted per chain
   if (pl.mode > MODE_CNF_EULER) { set_error("VJP: solvers dpm2 / dpm++2m have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->layer_norm) { set_error("VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
+  if (d->backbone != FRL_BACKBONE_MLP) { set_error("VJP: residual backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->dtype == FRL_DTYPE_BF16) {
     // bf16-MFMA VJP (csrc/sampler_bwd_bf16.hip): the narrow instantiation of the bf16 forward kernel
     if (pl.A > 16 || pl.C > 32 || pl.A + pl.C > 32) { set_error("bf16 VJP: x_dim <= 16 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
@@ -745,10 +811,11 @@ static int eval_plan(const FrlDesc* desc, EvalPlan& e) {
   d.n_hidden = desc->n_hidden;
   for (int l = 0; l < FRL_MAX_HIDDEN; ++l) d.hidden[l] = desc->hidden[l];
   d.act = desc->act; d.dtype = FRL_DTYPE_F32; d.layer_norm = desc->layer_norm; d.tile_policy = desc->tile_policy;
+  d.backbone = desc->backbone; d.res_multiplier = desc->res_multiplier;
   rc = validate_desc(&d);
   if (rc != FRL_OK) return rc;
   Plan& pl = e.pl;
-  pl.A = d.x_dim; pl.C = 0; pl.T = 1; pl.L = d.n_hidden; pl.D = 0; pl.Dp = 0;
+  pl.A = d.x_dim; pl.C = 0; pl.T = 1; pl.L = (d.backbone != FRL_BACKBONE_MLP) ? 1 : d.n_hidden; pl.D = 0; pl.Dp = 0;
   pl.AO = d.x_dim; pl.x_row0 = 0; pl.c_row0 = 0;
   pl.H = d.hidden[0];
   plan_layout(d, pl);
@@ -783,8 +850,13 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   if (pl.B == 0) return FRL_OK;
   if (bufs->x == nullptr || bufs->t == nullptr || bufs->out == nullptr) { set_error("bufs.x / t / out is NULL"); return FRL_EINVAL; }
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
-  for (int l = 0; l <= desc->n_hidden; ++l)
+  for (int l = 0; l <= pl.L; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  ResArgs ra;
+  if (desc->backbone != FRL_BACKBONE_MLP) {
+    rc = fill_res_args(desc, params, ra);
+    if (rc != FRL_OK) return rc;
+  }
   if (desc->time_embed != FRL_TEMB_NONE) {
     for (int k = 0; k < 2; ++k)
       if (params->tmlp_kernel[k] == nullptr || params->tmlp_bias[k] == nullptr) { set_error("params.tmlp_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
@@ -800,7 +872,7 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   pa.ws = ws; pa.plan = pl; pa.kind = FRL_KIND_CNF; pa.time_embed = FRL_TEMB_NONE;
   rc = launch_prepare(pa, stream);
   if (rc != FRL_OK) return rc;
-  if (desc->layer_norm) {
+  if (desc->layer_norm && desc->backbone == FRL_BACKBONE_MLP) {
     float* ln = ws + pl.off_ln;
     for (int l = 0; l < pl.L; ++l) {
       if (params->ln_scale[l] == nullptr || params->ln_bias[l] == nullptr) { set_error("params.ln_scale/ln_bias[%d] is NULL (desc.layer_norm = 1)", l); return FRL_EINVAL; }
@@ -829,7 +901,7 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   for (int l = 1; l < pl.L; ++l) { a.wh[l - 1] = params->kernel[l]; a.bh[l - 1] = params->bias[l]; }
   a.ws_coef = ws + pl.off_coef; a.ws_tb = ws + pl.off_tb; a.ws_w0p = ws + pl.off_w0p;
   a.ws_wlp = ws + pl.off_wlp; a.ws_wlq = ws + pl.off_wlq; a.ws_blp = ws + pl.off_blp;
-  a.ws_ln = desc->layer_norm ? ws + pl.off_ln : nullptr;
+  a.ws_ln = (desc->layer_norm && desc->backbone == FRL_BACKBONE_MLP) ? ws + pl.off_ln : nullptr;
   a.ln_post_act = desc->layer_norm == FRL_LN_POST_ACT ? 1 + desc->act : 0;
   a.B = pl.B; a.particles = 1; a.A = pl.A; a.C = 0; a.T = 1; a.L = pl.L; a.H = pl.H; a.TR = pl.TR;
   a.NE = 1; a.AO = pl.AO;
@@ -837,6 +909,7 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   a.mode = MODE_EVAL;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
   a.wl_raw = params->kernel[pl.L];
+  if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, stream);
   return launch_f32_network(a, desc->act, desc->tile_policy, stream);
 }
 
@@ -854,6 +927,7 @@ static int eval_bwd_plan(const FrlDesc* desc, EvalBwdPlan& q) {
   const Plan& pl = q.e.pl;
   if (pl.H != 256 || pl.TR != 32) { set_error("single-evaluation VJP: 256-wide predictors only"); return FRL_EUNSUPPORTED; }
   if (desc->layer_norm) { set_error("single-evaluation VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
+  if (desc->backbone != FRL_BACKBONE_MLP) { set_error("single-evaluation VJP: residual backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (desc->act != FRL_ACT_MISH && desc->act != FRL_ACT_SILU && desc->act != FRL_ACT_RELU) { set_error("single-evaluation VJP: activation %d (mish / silu / relu)", desc->act); return FRL_EUNSUPPORTED; }
   q.Cp = q.e.Dp + q.e.C;
   if (pl.AR > 12 || pl.A + q.Cp > 224) { set_error("single-evaluation VJP: x_dim <= 24 and x_dim + time_dim + cond_dim <= 224 required (got %d, %d)", pl.A, q.Cp); return FRL_EUNSUPPORTED; }

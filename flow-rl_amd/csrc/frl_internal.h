@@ -71,7 +71,8 @@ inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist = true);
 
 // allow_hoist = false: the condition rows of Dense_0 stay in the kernel's operand (the chain VJP contracts them per chain)
 inline int plan_from_desc(const FrlDesc& d, Plan& p, bool allow_hoist = true) {
-  p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps; p.L = d.n_hidden;
+  p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps;
+  p.L = (d.backbone != FRL_BACKBONE_MLP) ? 1 : d.n_hidden;   // residual classes: Dense_0 -> [blocks] -> Dense_1 around ONE 256-wide trunk
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
   p.AO = p.A; p.x_row0 = 0; p.c_row0 = p.A + p.Dp;
@@ -88,6 +89,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist) {
   p.AR = p.XR / p.KS;
   p.CK = (p.C + p.KS - 1) / p.KS;
   p.hoist = (allow_hoist && d.dtype == FRL_DTYPE_F32 && p.C > 0 && ((d.particles >= 4 && p.C >= 32) || p.CK > (p.TR == 32 ? 64 : 12))) ? 1 : 0;
+  if (d.backbone != FRL_BACKBONE_MLP && p.C > 0) p.hoist = 1;   // residual kernel: condition rows always enter per state
   if (p.hoist) p.CK = 0;
   p.K0p = p.XR + p.KS * p.CK;
   p.merged = (p.K0p <= SLAB_ROWS) ? 1 : 0;
@@ -113,7 +115,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist) {
   p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
   p.off_zs = take(p.hoist ? (size_t)d.n_states * p.H : 0);                     // hoisted cond slice of Dense_0, one row per state
   p.off_keys = take(d.rng_impl != FRL_RNG_NONE ? (size_t)p.NE * 2 : 0);        // per-iteration threefry keys (uint32 pairs)
-  p.off_ln = take(d.layer_norm ? (size_t)p.L * 2 * p.H : 0);                    // LayerNorm scale | bias rows, [L][2][H]
+  p.off_ln = take((d.layer_norm && d.backbone == FRL_BACKBONE_MLP) ? (size_t)p.L * 2 * p.H : 0);                    // LayerNorm scale | bias rows, [L][2][H]
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
   p.bf_nxk = (p.A <= 16 && p.C <= 32) ? 1 : 2;   // narrow instantiation <8, 2> or wide <16, 8>
   p.bf_cks = (p.bf_nxk == 1) ? 2 : 8;
@@ -149,6 +151,19 @@ struct KArgs {
   const void* ws_bf16;                    // bf16 weight stream image (bf16 variant only)
   int bf_nxk, bf_cks, bf_l0c, bf_ns;
 };
+
+// Residual-backbone part of the sampler's arguments (csrc/sampler_res.hip): block i = Dense (H, 4H) -> act -> Dense (4H, H)
+// around a residual, optionally behind a LayerNorm; kernels read in place.
+struct ResArgs {
+  int n_blocks, ln, final_ln, final_act;      // final_act: ResidualMLP's act before Dense_1; final_ln: Simba's LayerNorm there
+  const float* w1[FRL_MAX_HIDDEN]; const float* b1[FRL_MAX_HIDDEN];
+  const float* w2[FRL_MAX_HIDDEN]; const float* b2[FRL_MAX_HIDDEN];
+  const float* ln_scale[FRL_MAX_HIDDEN]; const float* ln_bias[FRL_MAX_HIDDEN];
+  const float* fln_scale; const float* fln_bias;
+};
+inline size_t res_lds_bytes(int NE, int n_blocks) {
+  return sizeof(float) * ((size_t)NE * 256 + LAST_PAD + (size_t)NE * COEF_STRIDE + (size_t)n_blocks * (1024 + 3 * 256) + 2 * 256);
+}
 
 // Arguments of the prepare kernel.
 struct PArgs {
@@ -334,6 +349,7 @@ void set_error(const char* fmt, ...);
 // launchers implemented in the .hip files
 int launch_prepare(const PArgs& a, hipStream_t stream);
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
+template <int ACT> int launch_sampler_res_act(const KArgs& a, const ResArgs& ra, hipStream_t stream);  // residual backbones (csrc/sampler_res.hip)
 template <int ACT> int launch_sampler_lat_act(const KArgs& a, int tile_rows, hipStream_t stream); // latency variant (4 waves per tile), one TU per activation
 // CU count of the current device (cached per thread and device)
 inline int device_cus() {

@@ -12,7 +12,7 @@ __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
 from . import random  # noqa: F401
-from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, PositionalEmbedding,  # noqa: F401
+from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, ResidualMLP, Simba, PositionalEmbedding,  # noqa: F401
                      LearnableFourierEmbedding, init_params, tree_from_numpy, tree_to)
 from ._lib import FlowRLHipError, FlowRLHipUnsupported  # noqa: F401
 from .critic import Ensemblize, ScalarCritic, critic_select, init_critic_params, sample_and_select  # noqa: F401

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FRL_ABI_VERSION = 4
+FRL_ABI_VERSION = 5
 FRL_MAX_HIDDEN = 8
 
 FRL_KIND_DDPM, FRL_KIND_CDDPM, FRL_KIND_CNF = 0, 1, 2
@@ -17,6 +17,7 @@ FRL_SOLVER_DDPM, FRL_SOLVER_DDIM, FRL_SOLVER_EULER, FRL_SOLVER_DPM2, FRL_SOLVER_
 FRL_TEMB_NONE, FRL_TEMB_POSITIONAL, FRL_TEMB_FOURIER = 0, 1, 2
 FRL_ACT = {"mish": 0, "silu": 1, "relu": 2, "gelu_tanh": 3, "gelu": 3, "tanh": 4, "elu": 5}
 FRL_DTYPE_F32, FRL_DTYPE_BF16 = 0, 1
+FRL_BACKBONE_MLP, FRL_BACKBONE_RESIDUAL, FRL_BACKBONE_SIMBA = 0, 1, 2
 FRL_TILE = {"auto": 0, "throughput": 1, "latency": 2, "latency32": 3, "latency16": 4}
 FRL_RNG = {"none": 0, "partitionable": 1, "legacy": 2}   # jax.random threefry layouts (include/flowrl_hip.h FRL_RNG_*)
 
@@ -33,6 +34,7 @@ class FrlDesc(C.Structure):
         ("hidden", C.c_int32 * FRL_MAX_HIDDEN), ("act", C.c_int32), ("clip", C.c_int32),
         ("x_min", C.c_float), ("x_max", C.c_float), ("dtype", C.c_int32), ("want_history", C.c_int32),
         ("cond_embed", C.c_int32), ("cond_in_dim", C.c_int32), ("tile_policy", C.c_int32), ("rng_impl", C.c_int32), ("layer_norm", C.c_int32),
+        ("backbone", C.c_int32), ("res_multiplier", C.c_int32),
     ]
 
 
@@ -42,6 +44,9 @@ class FrlParams(C.Structure):
         ("kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("bias", _fp * (FRL_MAX_HIDDEN + 1)),
         ("cond_kernel", _fp * 2), ("cond_bias", _fp * 2),
         ("ln_scale", _fp * FRL_MAX_HIDDEN), ("ln_bias", _fp * FRL_MAX_HIDDEN),
+        ("res_kernel", (_fp * 2) * FRL_MAX_HIDDEN), ("res_bias", (_fp * 2) * FRL_MAX_HIDDEN),
+        ("res_ln_scale", _fp * FRL_MAX_HIDDEN), ("res_ln_bias", _fp * FRL_MAX_HIDDEN),
+        ("final_ln_scale", _fp), ("final_ln_bias", _fp),
     ]
 
 

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from . import random as _random
-from .module import LearnableFourierEmbedding, PositionalEmbedding
+from .module import LearnableFourierEmbedding, PositionalEmbedding, Simba, is_residual
 
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 
@@ -125,6 +125,11 @@ def build_desc(network, *, kind: int, solver: int, steps: int, n_states: int, pa
     d.rng_impl = int(rng_impl)
     # Dense -> LayerNorm -> act (mlp.py:26-29), or FQL's Dense -> act -> LayerNorm (fql/network.py:26-30)
     d.layer_norm = (2 if getattr(pred, "ln_after_act", False) else 1) if pred.layer_norm else 0
+    if is_residual(pred):
+        if len(set(int(h) for h in pred.hidden_dims)) != 1:
+            raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "residual backbones: equal block widths only (no projection Dense)")
+        d.backbone = _lib.FRL_BACKBONE_SIMBA if isinstance(pred, Simba) else _lib.FRL_BACKBONE_RESIDUAL
+        d.res_multiplier = int(pred.multiplier)
     return d
 
 
@@ -150,6 +155,27 @@ def build_params(network, params: Dict, device: torch.device, keep: list) -> _li
         if isinstance(te, LearnableFourierEmbedding):
             fp.time_kernel = leaf(("time_embedding", "kernel"))
     n = len(network.predictor.hidden_dims)
+    pred, pn = network.predictor, network.predictor_name
+    if is_residual(pred):
+        for i in range(2):                # Dense_0: input projection, Dense_1: output layer (mlp.py:84,97; simba.py:49,62)
+            fp.kernel[i] = leaf((pn, f"Dense_{i}", "kernel"))
+            fp.bias[i] = leaf((pn, f"Dense_{i}", "bias"))
+        for i in range(n):
+            blk = f"{pred.block_name}_{i}"
+            for k in range(2):
+                fp.res_kernel[i][k] = leaf((pn, blk, f"Dense_{k}", "kernel"))
+                fp.res_bias[i][k] = leaf((pn, blk, f"Dense_{k}", "bias"))
+            if pred.layer_norm:
+                fp.res_ln_scale[i] = leaf((pn, blk, "LayerNorm_0", "scale"))
+                fp.res_ln_bias[i] = leaf((pn, blk, "LayerNorm_0", "bias"))
+        if isinstance(pred, Simba):
+            fp.final_ln_scale = leaf((pn, "LayerNorm_0", "scale"))
+            fp.final_ln_bias = leaf((pn, "LayerNorm_0", "bias"))
+        if network.cond_embedding is not None:
+            for i in range(2):
+                fp.cond_kernel[i] = leaf(("cond_embedding", f"Dense_{i}", "kernel"))
+                fp.cond_bias[i] = leaf(("cond_embedding", f"Dense_{i}", "bias"))
+        return fp
     for i in range(n + 1):
         fp.kernel[i] = leaf((network.predictor_name, f"Dense_{i}", "kernel"))
         fp.bias[i] = leaf((network.predictor_name, f"Dense_{i}", "bias"))
@@ -174,14 +200,33 @@ def check_param_shapes(network, params: Dict, x_dim: int, cond_dim: int) -> None
             if tuple(k.shape) != (cdims[i], cdims[i + 1]):
                 raise ValueError(f"cond_embedding/Dense_{i}/kernel {tuple(k.shape)}, expected {(cdims[i], cdims[i + 1])}")
         cond_dim = cdims[-1]
-    dims = [x_dim + d_time + cond_dim, *network.predictor.hidden_dims, x_dim]
     pp = params[network.predictor_name]
+    pred = network.predictor
+    if is_residual(pred):
+        h, m = int(pred.hidden_dims[0]), int(pred.multiplier)
+
+        def want(node, name, ks, bs):
+            k, b = node[name]["kernel"], node[name]["bias"]
+            if tuple(k.shape) != ks or tuple(b.shape) != bs:
+                raise ValueError(f"{network.predictor_name}/.../{name}: kernel {tuple(k.shape)} bias {tuple(b.shape)}, expected {ks} / {bs}")
+
+        want(pp, "Dense_0", (x_dim + d_time + cond_dim, h), (h,))
+        want(pp, "Dense_1", (h, x_dim), (x_dim,))
+        for i in range(len(pred.hidden_dims)):
+            blk = pp.get(f"{pred.block_name}_{i}")
+            if blk is None:
+                raise ValueError(f"{network.predictor_name}/{pred.block_name}_{i} missing from the params tree")
+            want(blk, "Dense_0", (h, m * h), (m * h,))
+            want(blk, "Dense_1", (m * h, h), (h,))
+        dims = []
+    else:
+        dims = [x_dim + d_time + cond_dim, *network.predictor.hidden_dims, x_dim]
     for i in range(len(dims) - 1):
         k, b = pp[f"Dense_{i}"]["kernel"], pp[f"Dense_{i}"]["bias"]
         if tuple(k.shape) != (dims[i], dims[i + 1]) or tuple(b.shape) != (dims[i + 1],):
             raise ValueError(f"{network.predictor_name}/Dense_{i}: kernel {tuple(k.shape)} bias {tuple(b.shape)}, "
                              f"expected {(dims[i], dims[i + 1])} / {(dims[i + 1],)} (input order x | time | cond)")
-    if network.predictor.layer_norm:
+    if network.predictor.layer_norm and not is_residual(pred):
         for i, h in enumerate(network.predictor.hidden_dims):
             ln = pp.get(f"LayerNorm_{i}")
             if ln is None or tuple(ln["scale"].shape) != (h,) or tuple(ln["bias"].shape) != (h,):

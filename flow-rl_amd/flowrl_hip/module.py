@@ -55,6 +55,43 @@ class MLP:
 
 
 @dataclass
+class ResidualMLP:
+    """flowrl/module/mlp.py:67-98.  hidden_dims = one entry per residual block (all equal: a block whose width differs
+    from its input's gets a projection Dense the fused kernel does not build)."""
+    hidden_dims: Sequence[int] = field(default_factory=list)
+    output_dim: int = 0
+    multiplier: int = 4
+    activation: Union[str, Callable] = "relu"
+    layer_norm: bool = False
+    dropout: Optional[float] = None
+    block_name = "ResidualLinear"
+
+    @property
+    def act_name(self) -> str:
+        return _act_name(self.activation)
+
+
+@dataclass
+class Simba:
+    """flowrl/module/simba.py:28-63 (https://arxiv.org/abs/2410.09754): LayerNorm in every block and before the output layer."""
+    hidden_dims: Sequence[int] = field(default_factory=list)
+    output_dim: int = 0
+    activation: Union[str, Callable] = "relu"
+    multiplier: int = 4
+    layer_norm = True       # always (simba.py:22)
+    dropout = None
+    block_name = "SimbaBlock"
+
+    @property
+    def act_name(self) -> str:
+        return _act_name(self.activation)
+
+
+def is_residual(pred) -> bool:
+    return isinstance(pred, (ResidualMLP, Simba))
+
+
+@dataclass
 class PositionalEmbedding:
     output_dim: int
     max_positions: int = 10000
@@ -67,7 +104,7 @@ class LearnableFourierEmbedding:
 
 @dataclass
 class DDPMBackbone:
-    noise_predictor: MLP
+    noise_predictor: Union[MLP, ResidualMLP, Simba]
     time_embedding: Optional[Union[PositionalEmbedding, LearnableFourierEmbedding]] = None
     cond_embedding: Optional[MLP] = None
     predictor_name = "noise_predictor"
@@ -79,7 +116,7 @@ class DDPMBackbone:
 
 @dataclass
 class FlowBackbone:
-    vel_predictor: MLP
+    vel_predictor: Union[MLP, ResidualMLP, Simba]
     time_embedding: Optional[Union[PositionalEmbedding, LearnableFourierEmbedding]] = None
     cond_embedding: Optional[MLP] = None
     predictor_name = "vel_predictor"
@@ -129,6 +166,28 @@ def init_params(network, x_dim: int, cond_dim: int, seed: int = 0, bias_std: flo
         cdims = [cond_dim, *ce.hidden_dims]
         p["cond_embedding"] = {f"Dense_{i}": _dense(gen, cdims[i], cdims[i + 1], bias_std) for i in range(len(ce.hidden_dims))}
         cond_dim = cdims[-1]
+    if is_residual(pred):
+        # flax auto-naming inside the @nn.compact bodies: Dense_0 (input projection), <Block>_i/{LayerNorm_0, Dense_0, Dense_1},
+        # [LayerNorm_0 (Simba)], Dense_1 (output).  Kernels orthogonal(sqrt 2) for ResidualMLP; Simba's he_normal /
+        # orthogonal(1) (simba.py:23-25,49,62) only change the scale of the random test weights, not the layout.
+        h, m = int(pred.hidden_dims[0]), int(pred.multiplier)
+        q: Dict = {"Dense_0": _dense(gen, x_dim + d_time + cond_dim, h, bias_std)}
+
+        def _ln():
+            sc = torch.ones(h) if bias_std == 0.0 else 1.0 + bias_std * torch.randn(h, generator=gen)
+            bi = torch.zeros(h) if bias_std == 0.0 else bias_std * torch.randn(h, generator=gen)
+            return {"scale": sc.to(torch.float32), "bias": bi.to(torch.float32)}
+
+        for i in range(len(pred.hidden_dims)):
+            blk = {"Dense_0": _dense(gen, h, m * h, bias_std), "Dense_1": _dense(gen, m * h, h, bias_std)}
+            if pred.layer_norm:
+                blk["LayerNorm_0"] = _ln()
+            q[f"{pred.block_name}_{i}"] = blk
+        if isinstance(pred, Simba):
+            q["LayerNorm_0"] = _ln()
+        q["Dense_1"] = _dense(gen, h, x_dim, bias_std)
+        p[network.predictor_name] = q
+        return tree_to(p, device)
     dims = [x_dim + d_time + cond_dim, *pred.hidden_dims, x_dim]
     p[network.predictor_name] = {f"Dense_{i}": _dense(gen, dims[i], dims[i + 1], bias_std) for i in range(len(dims) - 1)}
     if pred.layer_norm:   # flax.linen.LayerNorm: scale = ones, bias = zeros (bias_std > 0 perturbs both, for tests)

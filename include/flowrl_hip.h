@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FRL_ABI_VERSION 4
+#define FRL_ABI_VERSION 5
 #define FRL_MAX_HIDDEN 8 /* hidden Dense layers of the predictor MLP (mlp.py:25) */
 
 /* error codes */
@@ -86,6 +86,11 @@ extern "C" {
 /* Static description of one sampler call — the analogue of the reference's jit static_argnames
  * plus the pytree_node=False fields of DDPM / ContinuousDDPM / ContinuousNormalizingFlow
  * (ddpm.py:103-107, continuous_ddpm.py:51-59, cnf.py:50-54). */
+/* predictor classes (the noise_predictor / vel_predictor of a DDPMBackbone / FlowBackbone) */
+#define FRL_BACKBONE_MLP 0       /* flowrl/module/mlp.py:10-34 (and FQL's variant) */
+#define FRL_BACKBONE_RESIDUAL 1  /* ResidualMLP, flowrl/module/mlp.py:37-98: Dense_0, ResidualLinear_i, act, Dense_1 */
+#define FRL_BACKBONE_SIMBA 2     /* Simba, flowrl/module/simba.py:10-63: Dense_0, SimbaBlock_i, LayerNorm_0, Dense_1 */
+
 typedef struct FrlDesc {
   int32_t abi_version; /* FRL_ABI_VERSION */
   int32_t kind;        /* FRL_KIND_*   */
@@ -114,6 +119,10 @@ typedef struct FrlDesc {
   int32_t layer_norm;   /* FRL_LN_PRE_ACT (1): the predictor MLP is Dense -> LayerNorm -> act (MLP(layer_norm=True), mlp.py:26-29);
                            FRL_LN_POST_ACT (2): Dense -> act -> LayerNorm (FQL's MLP, agent/offline/fql/network.py:26-30).
                            flax LayerNorm: eps 1e-6, scale and bias; the variance is taken about the mean — f32 builds, forward only */
+  int32_t backbone;     /* FRL_BACKBONE_*: the predictor's class.  For the residual classes n_hidden / hidden[] are the BLOCKS
+                           (len(hidden_dims), each 256 wide) and layer_norm says whether ResidualLinear normalises its input
+                           (ResidualMLP(layer_norm=True), dac.py:201-207); Simba always does.  f32, forward only */
+  int32_t res_multiplier; /* expansion of a residual block (mlp.py:39, simba.py:13); 4 in every reference config, the only value built */
 } FrlDesc;
 
 /* Leaves of the Flax parameter tree produced by Model.create (module/model.py:31-60) for a
@@ -130,6 +139,15 @@ typedef struct FrlParams {
   /* params/<predictor>/LayerNorm_i/{scale,bias}, (hidden[i],) each, i = 0..L-1; read when desc.layer_norm = 1 */
   const float* ln_scale[FRL_MAX_HIDDEN];
   const float* ln_bias[FRL_MAX_HIDDEN];
+  /* Residual backbones (desc.backbone != FRL_BACKBONE_MLP): kernel[0] / bias[0] = params/<predictor>/Dense_0 (the input
+   * projection, rows x | time | cond), kernel[1] / bias[1] = .../Dense_1 (the output layer), and per block i =
+   * .../ResidualLinear_i or .../SimbaBlock_i: Dense_0 (H, m H), Dense_1 (m H, H), LayerNorm_0 (H,) */
+  const float* res_kernel[FRL_MAX_HIDDEN][2];
+  const float* res_bias[FRL_MAX_HIDDEN][2];
+  const float* res_ln_scale[FRL_MAX_HIDDEN];
+  const float* res_ln_bias[FRL_MAX_HIDDEN];
+  const float* final_ln_scale; /* Simba: params/<predictor>/LayerNorm_0/{scale,bias} (simba.py:58) */
+  const float* final_ln_bias;
 } FrlParams;
 
 /* Noise-schedule tables, each (T+1,) float32 on the device.

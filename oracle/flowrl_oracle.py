@@ -246,6 +246,30 @@ def mlp_apply(p: Dict, x, n_hidden: int, activation, has_output: bool, ln: bool 
     return x
 
 
+def residual_mlp_apply(p: Dict, x, n_blocks: int, activation, ln: bool):
+    """ResidualMLP.__call__ (flowrl/module/mlp.py:77-98) with ResidualLinear (mlp.py:46-64), dropout off, equal block
+    widths (residual.shape == x.shape, so no projection Dense): x = Dense_0(x); per block x = x + Dense_1(act(Dense_0([LN](x))));
+    out = Dense_1(act(x)).  Flax names: Dense_0, ResidualLinear_i/{LayerNorm_0, Dense_0, Dense_1}, Dense_1."""
+    x = dense(p["Dense_0"], x)
+    for i in range(n_blocks):
+        b = p[f"ResidualLinear_{i}"]
+        y = layer_norm(b["LayerNorm_0"], x) if ln else x
+        y = activation(dense(b["Dense_0"], y))
+        x = x + dense(b["Dense_1"], y)
+    return dense(p["Dense_1"], activation(x))
+
+
+def simba_apply(p: Dict, x, n_blocks: int, activation):
+    """Simba.__call__ (flowrl/module/simba.py:42-63) with SimbaBlock (simba.py:15-26): x = Dense_0(x); per block
+    x = x + Dense_1(act(Dense_0(LN(x)))); out = Dense_1(LayerNorm_0(x)) — no activation before the output layer."""
+    x = dense(p["Dense_0"], x)
+    for i in range(n_blocks):
+        b = p[f"SimbaBlock_{i}"]
+        y = activation(dense(b["Dense_0"], layer_norm(b["LayerNorm_0"], x)))
+        x = x + dense(b["Dense_1"], y)
+    return dense(p["Dense_1"], layer_norm(p["LayerNorm_0"], x))
+
+
 @dataclass
 class BackboneSpec:
     """Static description of a DDPMBackbone / FlowBackbone instance."""
@@ -258,6 +282,9 @@ class BackboneSpec:
     predictor_name: str = "noise_predictor"         # "vel_predictor" for FlowBackbone
     layer_norm: bool = False                        # MLP(layer_norm=True) predictor (mlp.py:27-28)
     ln_after_act: bool = False                      # FQL's MLP: Dense -> act -> LayerNorm (fql/network.py:26-30)
+    backbone: str = "mlp"                           # "mlp" | "residual" (ResidualMLP, mlp.py:67-98) | "simba" (simba.py:28-63);
+                                                    # for the residual classes hidden_dims lists the BLOCKS
+    multiplier: int = 4
     bf16_operands: bool = False                     # emulate the bf16-MFMA variant: predictor Dense operands rounded to
                                                     # bf16 (RNE), products / sums / biases / time slice / activations exact
 
@@ -303,6 +330,10 @@ def backbone_apply(spec: BackboneSpec, params: Dict, x, time, condition=None):
         inputs = np.concatenate([x, time, condition], axis=-1)
     else:
         inputs = np.concatenate([x, time], axis=-1)
+    if spec.backbone == "residual":
+        return residual_mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, spec.layer_norm)
+    if spec.backbone == "simba":
+        return simba_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act)
     return mlp_apply(params[spec.predictor_name], inputs, len(spec.hidden_dims), act, has_output=True, ln=spec.layer_norm,
                      ln_after_act=spec.ln_after_act)
 
@@ -580,6 +611,21 @@ def make_params(spec: BackboneSpec, cond_dim: int, seed: int, dtype=np.float32, 
         dims = [cond_in_dim] + list(spec.cond_hidden)
         p["cond_embedding"] = {f"Dense_{i}": _dense_params(rng, dims[i], dims[i + 1], dtype) for i in range(len(spec.cond_hidden))}
         cond_dim = spec.cond_hidden[-1]
+    if spec.backbone != "mlp":
+        h, m = int(spec.hidden_dims[0]), int(spec.multiplier)
+        block = "SimbaBlock" if spec.backbone == "simba" else "ResidualLinear"
+        ln = spec.layer_norm or spec.backbone == "simba"
+        lnp = lambda: {"scale": (1.0 + 0.2 * rng.standard_normal(h)).astype(dtype), "bias": (0.1 * rng.standard_normal(h)).astype(dtype)}
+        q: Dict = {"Dense_0": _dense_params(rng, spec.x_dim + d_time + cond_dim, h, dtype)}
+        for i in range(len(spec.hidden_dims)):
+            q[f"{block}_{i}"] = {"Dense_0": _dense_params(rng, h, m * h, dtype), "Dense_1": _dense_params(rng, m * h, h, dtype)}
+            if ln:
+                q[f"{block}_{i}"]["LayerNorm_0"] = lnp()
+        if spec.backbone == "simba":
+            q["LayerNorm_0"] = lnp()
+        q["Dense_1"] = _dense_params(rng, h, spec.x_dim, dtype)
+        p[spec.predictor_name] = q
+        return p
     dims = [spec.x_dim + d_time + cond_dim] + list(spec.hidden_dims) + [spec.x_dim]
     p[spec.predictor_name] = {f"Dense_{i}": _dense_params(rng, dims[i], dims[i + 1], dtype) for i in range(len(dims) - 1)}
     if spec.layer_norm:   # drawn AFTER everything else so that specs without LayerNorm keep their parameter streams

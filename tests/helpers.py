@@ -33,6 +33,7 @@ class Case:
     tile: str = "auto"             # FrlDesc.tile_policy of the product run: auto | throughput | latency
     ln: bool = False               # MLP(layer_norm=True) predictor: Dense -> LayerNorm -> act (mlp.py:26-29)
     ln_post: bool = False          # with ln: FQL's order Dense -> act -> LayerNorm (fql/network.py:26-30)
+    backbone: str = "mlp"          # "mlp" | "residual" (ResidualMLP) | "simba": `hidden` then lists the blocks
 
     @property
     def spec(self):
@@ -40,7 +41,7 @@ class Case:
                                 time_embedding=self.temb, time_dim=64,
                                 cond_hidden=[128, 128] if self.cond_embed else None,
                                 predictor_name="vel_predictor" if self.kind == "cnf" else "noise_predictor",
-                                bf16_operands=self.bf16, layer_norm=self.ln, ln_after_act=self.ln_post)
+                                bf16_operands=self.bf16, layer_norm=self.ln, ln_after_act=self.ln_post, backbone=self.backbone)
 
 
 def make_inputs(c: Case):
@@ -79,6 +80,8 @@ def permuted_hidden_units(c: Case, params, seed: int):
     LayerNorm rows, rows of Dense_{l+1}): mathematically identical outputs, another float32 summation order."""
     rng = np.random.default_rng(seed)
     name = c.spec.predictor_name
+    if c.backbone != "mlp":
+        return permuted_residual_units(c, params, rng)
     out = {k: (dict(v) if isinstance(v, dict) else v) for k, v in params.items()}
     pp = {k: dict(v) for k, v in params[name].items()}
     L = len(c.hidden)
@@ -90,6 +93,31 @@ def permuted_hidden_units(c: Case, params, seed: int):
             pp[f"LayerNorm_{l}"]["scale"] = pp[f"LayerNorm_{l}"]["scale"][perm]
             pp[f"LayerNorm_{l}"]["bias"] = pp[f"LayerNorm_{l}"]["bias"][perm]
         pp[f"Dense_{l + 1}"]["kernel"] = pp[f"Dense_{l + 1}"]["kernel"][perm, :]
+    out[name] = pp
+    return out
+
+
+def permuted_residual_units(c: Case, params, rng):
+    """Residual classes: renumber the 4H expansion units of every block (columns of its Dense_0, rows of its Dense_1) and
+    the trunk's H units (every tensor that reads or writes the residual stream)."""
+    name = c.spec.predictor_name
+    out = {k: (dict(v) if isinstance(v, dict) else v) for k, v in params.items()}
+    pp = {k: ({kk: (dict(vv) if isinstance(vv, dict) else vv) for kk, vv in v.items()}) for k, v in params[name].items()}
+    h = c.hidden[0]
+    trunk = rng.permutation(h)
+    pp["Dense_0"]["kernel"] = pp["Dense_0"]["kernel"][:, trunk]
+    pp["Dense_0"]["bias"] = pp["Dense_0"]["bias"][trunk]
+    pp["Dense_1"]["kernel"] = pp["Dense_1"]["kernel"][trunk, :]
+    if "LayerNorm_0" in pp:
+        pp["LayerNorm_0"] = {k: v[trunk] for k, v in pp["LayerNorm_0"].items()}
+    for key in list(pp):
+        if "_" in key and key.split("_")[0] in ("ResidualLinear", "SimbaBlock"):
+            b = pp[key]
+            wide = rng.permutation(b["Dense_0"]["kernel"].shape[1])
+            b["Dense_0"] = {"kernel": b["Dense_0"]["kernel"][trunk][:, wide], "bias": b["Dense_0"]["bias"][wide]}
+            b["Dense_1"] = {"kernel": b["Dense_1"]["kernel"][wide][:, trunk], "bias": b["Dense_1"]["bias"][trunk]}
+            if "LayerNorm_0" in b:
+                b["LayerNorm_0"] = {k: v[trunk] for k, v in b["LayerNorm_0"].items()}
     out[name] = pp
     return out
 
@@ -120,7 +148,12 @@ def product_model(c: Case, params, device="cuda"):
         te = fh.PositionalEmbedding(output_dim=64)
     elif c.temb == "learnable_fourier":
         te = fh.LearnableFourierEmbedding(output_dim=64)
-    mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act, layer_norm=c.ln, ln_after_act=c.ln_post)
+    if c.backbone == "residual":
+        mlp = fh.ResidualMLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act, layer_norm=c.ln)
+    elif c.backbone == "simba":
+        mlp = fh.Simba(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act)
+    else:
+        mlp = fh.MLP(hidden_dims=list(c.hidden), output_dim=c.A, activation=c.act, layer_norm=c.ln, ln_after_act=c.ln_post)
     ce = fh.MLP(hidden_dims=[128, 128], activation=c.act) if c.cond_embed else None
     tparams = fh.tree_from_numpy(params, device)
     inputs = (np.ones((1, c.A)), np.zeros((1, 1)), np.ones((1, c.S)) if c.S > 0 else None)

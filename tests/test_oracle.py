@@ -411,3 +411,28 @@ def test_layer_norm_known_answers():
     a = orc.backbone_apply(spec, prm, xx, t, cd)
     b = orc.backbone_apply(orc.BackboneSpec(hidden_dims=[256, 256], x_dim=3), prm, xx, t, cd)
     assert a.shape == (4, 3) and np.abs(a - b).max() > 1e-3
+
+
+def test_residual_backbones_against_torch_restatement():
+    """residual_mlp_apply / simba_apply (mlp.py:37-98, simba.py:10-63) against an independent torch float64 restatement
+    built from torch.nn.functional primitives (layer_norm, linear): structure, LayerNorm placement, head."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    for backbone, ln in (("residual", True), ("residual", False), ("simba", True)):
+        spec = orc.BackboneSpec(hidden_dims=[256, 256], x_dim=3, activation="mish", time_embedding=None, backbone=backbone, layer_norm=ln)
+        p = orc.cast_tree(orc.make_params(spec, 5, seed=3), np.float64)
+        x, t, c = rng.standard_normal((7, 3)), rng.uniform(size=(7, 1)), rng.standard_normal((7, 5))
+        got = orc.backbone_apply(spec, p, x, t, c)
+        q = p["noise_predictor"]
+        T = lambda a: torch.from_numpy(np.asarray(a))
+        lin = lambda d, v: F.linear(v, T(d["kernel"]).T, T(d["bias"]))
+        lnf = lambda d, v: F.layer_norm(v, (256,), T(d["scale"]), T(d["bias"]), eps=1e-6)
+        h = lin(q["Dense_0"], T(np.concatenate([x, t, c], -1)))
+        blk = "SimbaBlock" if backbone == "simba" else "ResidualLinear"
+        for i in range(2):
+            b = q[f"{blk}_{i}"]
+            y = lnf(b["LayerNorm_0"], h) if (ln or backbone == "simba") else h
+            h = h + lin(b["Dense_1"], F.mish(lin(b["Dense_0"], y)))
+        want = lin(q["Dense_1"], lnf(q["LayerNorm_0"], h) if backbone == "simba" else F.mish(h))
+        assert np.abs(got - want.numpy()).max() <= 1e-12 * max(1.0, np.abs(got).max()), backbone
