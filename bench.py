@@ -55,6 +55,15 @@ WORKLOADS = {
     "cfg5": dict(desc="DQL backprop-through-chain VJP (cfg2 shapes: obs 11, act 3, 256x3 mish, vp, T=5, clip +-1, B=262144/GPU), "
                       "forward+backward", kind="ddpm", A=3, S=11, T=5, B=262144, particles=1, hidden=[256, 256, 256],
                  act="mish", temb="positional", schedule="vp", clip=True, x_min=-1.0, x_max=1.0, cond_embed=False, vjp=True),
+    # residual backbones, not BASELINE configs: DAC / BDPO with diffusion.resnet (dac.py:200-207) at the
+    # cfg2 geometry, and backbone_cls: simba behind DACER's embeddings (dacer.py:247-266)
+    "res_dac": dict(desc="DAC resnet DDPM hopper (obs 11, act 3, ResidualMLP 2 x [256 -> 1024 -> 256] mish + LayerNorm, vp, T=5, "
+                         "clip +-1, B=262144/GPU)", kind="ddpm", A=3, S=11, T=5, B=262144, particles=1, hidden=[256, 256], act="mish",
+                    temb="positional", schedule="vp", clip=True, x_min=-1.0, x_max=1.0, cond_embed=False, backbone="residual", ln=True),
+    "simba_dacer": dict(desc="DACER simba ContinuousDDPM humanoid (obs 376 -> cond-embed 128, act 17, Simba 2 blocks relu, Fourier-64, "
+                             "cosine, T=20, clip +-1, 1024 states x 64 particles/GPU)", kind="cddpm", A=17, S=376, T=20, B=1024 * 64,
+                        particles=64, hidden=[256, 256], act="relu", temb="learnable_fourier", schedule="cosine", clip=True,
+                        x_min=-1.0, x_max=1.0, cond_embed=True, backbone="simba"),
 }
 
 
@@ -63,7 +72,12 @@ def build_model(w, device, seed=0):
     from flowrl_hip.flow import DDPM, ContinuousDDPM, ContinuousNormalizingFlow
     te = {"positional": fh.PositionalEmbedding(output_dim=64), "learnable_fourier": fh.LearnableFourierEmbedding(output_dim=64),
           None: None}[w["temb"]]
-    mlp = fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"])
+    if w.get("backbone") == "residual":
+        mlp = fh.ResidualMLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"], layer_norm=bool(w.get("ln")))
+    elif w.get("backbone") == "simba":
+        mlp = fh.Simba(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"])
+    else:
+        mlp = fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"])
     ce = fh.MLP(hidden_dims=[128, 128], activation=w["act"]) if w["cond_embed"] else None
     inputs = (np.ones((1, w["A"])), np.zeros((1, 1)), np.ones((1, w["S"])))
     if w["kind"] == "cnf":
@@ -229,7 +243,8 @@ def cpu_baseline(w, budget_s=15.0):
         cores = os.cpu_count() or 1
     spec = orc.BackboneSpec(hidden_dims=w["hidden"], x_dim=w["A"], activation=w["act"], time_embedding=w["temb"],
                             cond_hidden=[128, 128] if w["cond_embed"] else None,
-                            predictor_name="vel_predictor" if w["kind"] == "cnf" else "noise_predictor")
+                            predictor_name="vel_predictor" if w["kind"] == "cnf" else "noise_predictor",
+                            backbone=w.get("backbone", "mlp"), layer_norm=bool(w.get("ln")))
     params = orc.make_params(spec, w["S"], seed=0, cond_in_dim=w["S"])
     rng = np.random.default_rng(0)
     kw = dict(steps=w["T"], clip_sampler=w["clip"], x_min=w["x_min"], x_max=w["x_max"])
@@ -444,6 +459,8 @@ def main():
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         lat = args.tile_policy.startswith("latency") or (args.tile_policy == "auto" and (B + 15) // 16 <= ncu) or (args.tile_policy == "auto" and -(-((B + 31) // 32) // ncu) <= 3 * -(-((B + 31) // 32) // (4 * ncu)))
         kname = "frl_sampler_lat_kernel" if (lat and args.dtype == "f32") else "frl_sampler_rs_kernel"
+        if w.get("backbone", "mlp") != "mlp":
+            kname = "frl_sampler_res_kernel"
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
             f_ms, b_ms = vjp_parts_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
