@@ -118,7 +118,7 @@ def sample(model, w, xT, cond, noise):
 def vjp_step(model, w, xT, cond, noise, g):
     """One DQL actor-update worth of sampler work: forward keeping history[0], then the chain VJP."""
     cd = w.get("dtype", "f32")
-    stash = cd == "f32" and not w.get("recompute")     # f32: the training forward keeps the stash, the backward only sweeps
+    stash = not w.get("recompute")     # the training forward keeps the stash, the backward only sweeps
     _, x0, hist = model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, keep_for_vjp=stash)
     grads, _ = model.sample_vjp(hist[0], g, cond, "ddpm", want_gxT=False, compute_dtype=cd, ctx=hist[2] if stash else None)
     return x0, grads
@@ -126,10 +126,10 @@ def vjp_step(model, w, xT, cond, noise, g):
 
 def vjp_parts_ms(model, w, xT, cond, noise, g, iters):
     """Average durations of the two calls of a VJP step, events on the launch stream: the forward that keeps what the
-    backward needs (f32: frl_sampler_fwd_train; bf16 / --recompute: frl_sampler_fwd with history) and the backward call
+    backward needs (frl_sampler_fwd_train; --recompute: frl_sampler_fwd with history) and the backward call
     (frl_sampler_bwd: [recompute +] sweep + dW + reduce + time-branch kernels)."""
     cd = w.get("dtype", "f32")
-    stash = cd == "f32" and not w.get("recompute")
+    stash = not w.get("recompute")
 
     def fwd():
         return model.sample(None, xT, cond, True, "ddpm", params=model.params, noise=noise, history=True, compute_dtype=cd, keep_for_vjp=stash)[2]
@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
-    ap.add_argument("--recompute", action="store_true", help="cfg5 f32: plain forward with history + a backward that recomputes every step (round-1 path) instead of the training forward's stash")
+    ap.add_argument("--recompute", action="store_true", help="cfg5: plain forward with history + a backward that recomputes every step (round-1 path) instead of the training forward's stash")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU / gloo stand-in of the rank body (no GPU, not a measurement)")
     args = ap.parse_args()
 
@@ -464,8 +464,10 @@ def main():
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
             f_ms, b_ms = vjp_parts_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
-            stash = args.dtype == "f32" and not args.recompute
-            kname = ("frl_sampler_fwd (bf16, history) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel [recompute + backward] + frl_bwd_dw_bf16_kernel + frl_bwd_reduce_kernel)"
+            stash = not args.recompute
+            kname = (("frl_sampler_fwd_train (frl_bwd_sweep_bf16_kernel<PHASE 1>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel<PHASE 2> + frl_bwd_dw_bf16_kernel + frl_bwd_reduce_kernel)"
+                      if stash else
+                      "frl_sampler_fwd (bf16, history) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel<PHASE 0> [recompute + backward] + frl_bwd_dw_bf16_kernel + frl_bwd_reduce_kernel)")
                      if args.dtype == "bf16" else
                      "frl_sampler_fwd_train (frl_bwd_sweep_kernel<PHASE 1>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 2> + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)"
                      if stash else

@@ -533,12 +533,13 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
   int rc = validate_bwd(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
-  if (desc->dtype != FRL_DTYPE_F32) { set_error("training forward: f32 only (bf16: frl_sampler_fwd + frl_sampler_bwd, which recomputes)"); return FRL_EUNSUPPORTED; }
   if (!desc->want_history) { set_error("training forward: desc.want_history must be 1 (the backward reads xt_hist / eps_hist)"); return FRL_EINVAL; }
   BwdPlan bp;
   BwdPlan16 bp16;
   memset(&bp16, 0, sizeof(bp16));
-  bwd_plan_from_desc(*desc, bp);
+  const bool bf16 = desc->dtype == FRL_DTYPE_BF16;
+  if (bf16) { bwd16_plan_from_desc(*desc, bp16); bp.f = bp16.f; bp.total_floats = bp16.total_floats; }
+  else bwd_plan_from_desc(*desc, bp);
   const Plan& pl = bp.f;
   if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
   if (workspace_bytes < bp.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B (frl_bwd_workspace_bytes)", workspace_bytes, bp.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
@@ -567,7 +568,7 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
     if (rc != FRL_OK) return rc;
   }
   BArgs b;
-  fill_bwd_args(desc, params, pl, bp, bp16, false, ws, bufs->cond, b);
+  fill_bwd_args(desc, params, pl, bp, bp16, bf16, ws, bufs->cond, b);
   KArgs& a = b.k;
   a.xT = bufs->xT; a.x0 = bufs->x0; a.xt_hist = bufs->xt_hist; a.eps_hist = bufs->eps_hist;
   const bool draw = rng && needs_noise && bufs->noise == nullptr;
@@ -582,7 +583,7 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
       a.rng_total = bufs->rng_total_chains > 0 ? bufs->rng_total_chains : pl.B;
     }
   }
-  return launch_sampler_bwd(*desc, b, 1, stream);
+  return bf16 ? launch_sampler_bwd_bf16(*desc, b, 1, stream) : launch_sampler_bwd(*desc, b, 1, stream);
 }
 
 int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlBwdBufs* bufs,
@@ -604,7 +605,6 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   if (bufs->xt_hist == nullptr || bufs->g_x0 == nullptr || bufs->grad_tb == nullptr) { set_error("bufs.xt_hist / g_x0 / grad_tb is NULL"); return FRL_EINVAL; }
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
   const bool stash = bufs->have_stash != 0;
-  if (stash && bf16) { set_error("have_stash: the bf16 VJP has no training forward (it recomputes)"); return FRL_EUNSUPPORTED; }
   if (stash && bufs->eps_hist == nullptr) { set_error("have_stash = 1 needs bufs.eps_hist (history[1] of frl_sampler_fwd_train)"); return FRL_EINVAL; }
   if (!stash && bwd_needs_stash(desc, pl)) {
     set_error("VJP: x_dim %d / %d condition rows%s: run the forward with frl_sampler_fwd_train and pass have_stash = 1 (the recompute path covers x_dim <= 8, <= 24 condition rows, no cond_embedding)",
@@ -636,7 +636,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   b.xt_hist = bufs->xt_hist; b.g_x0 = bufs->g_x0; b.g_xT = bufs->g_xT; b.eps_hist = bufs->eps_hist;
   for (int l = 0; l <= pl.L; ++l) { b.grad_kernel[l] = bufs->grad_kernel[l]; b.grad_bias[l] = bufs->grad_bias[l]; }
   b.grad_tb = bufs->grad_tb;
-  rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stream) : launch_sampler_bwd(*desc, b, stash ? 2 : 0, stream);
+  rc = bf16 ? launch_sampler_bwd_bf16(*desc, b, stash ? 2 : 0, stream) : launch_sampler_bwd(*desc, b, stash ? 2 : 0, stream);
   if (rc != FRL_OK) return rc;
   if (desc->cond_embed) {
     // dL/dcfeat (per chain, summed over steps by the sweep) -> the two embedding layers (bufs.cond = the raw observations)

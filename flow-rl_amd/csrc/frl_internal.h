@@ -320,7 +320,11 @@ inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
 }
 
 int launch_prepare_bwd_bf16(const FrlParams& p, const BwdPlan16& bp, float* ws, hipStream_t stream);
-int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& a, hipStream_t stream);
+template <int PHASE> int launch_bwd16_sweep_phase(const FrlDesc& d, const BArgs& b, hipStream_t stream);
+template <> int launch_bwd16_sweep_phase<0>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
+template <> int launch_bwd16_sweep_phase<1>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
+template <> int launch_bwd16_sweep_phase<2>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
+int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& b, int phase, hipStream_t stream);   // 0 recompute + backward, 1 training forward, 2 backward from the stash
 
 // time-branch VJP (csrc/time_bwd.hip): one workgroup, double-precision scratch of (1 + 7 D) T doubles
 struct TBArgs {

@@ -19,10 +19,23 @@
 //                                 transposed through LDS ([feature][32 chains] bf16), each workgroup owns the whole
 //                                 256 x 256 tile of a layer in accumulators over its range of tile-steps, one
 //                                 float-atomic flush per layer.  HBM-bound (it streams the stash once).
+//
+// Three builds of the sweep (FRL_BWD16_PHASE, one translation unit each, as csrc/sampler_bwd.hip):
+//   0  recompute + backward from xt_hist alone (the forward was a plain frl_sampler_fwd with history)
+//   1  TRAINING FORWARD (frl_sampler_fwd_train, dtype bf16): the sampler itself, steps 0 .. T-1 over the forward image only,
+//      writing x0 / history and the stash of h = act(z) and act'(z) the backward reads
+//   2  backward from that stash: steps T-1 .. 0 over the backward image only, eps from eps_hist — no forward MFMAs, no
+//      activation VALU
 #include "frl_bf16.h"
+#include "frl_rng.h"
+
+#ifndef FRL_BWD16_PHASE
+#error "compile with -DFRL_BWD16_PHASE=0|1|2"
+#endif
 
 namespace frl {
 
+#if FRL_BWD16_PHASE == 0
 // ---- backward weight stream image ---------------------------------------------------------------------------------
 struct PBbArgs {
   const float* kernel[FRL_MAX_HIDDEN + 1];
@@ -65,6 +78,8 @@ int launch_prepare_bwd_bf16(const FrlParams& prm, const BwdPlan16& bp, float* ws
   if (e != hipSuccess) { set_error("bf16 bwd prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
 }
+
+#endif  // FRL_BWD16_PHASE == 0
 
 // ---- activation and derivative (h bit-identical to the forward kernel's act_bf for the same z) ---------------------
 template <int ACT>
@@ -139,7 +154,7 @@ __device__ __forceinline__ void layer_g(BFun&& bfun, Init&& init, Epi&& epi, Nex
   epi(std::integral_constant<int, NOB - 1>{}, acc[(NOB - 1) & 1]);
 }
 
-template <int ACT>
+template <int ACT, int PHASE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 frl_bwd_sweep_bf16_kernel(const BArgs b) {
   constexpr int H = 256, NRX = 8, CKS = 2, K0 = 1 + CKS, NT = 512;
@@ -165,24 +180,37 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
   for (int idx = tid; idx < a.T * COEF_STRIDE; idx += NT) s_coef[idx] = a.ws_coef[idx];
   __syncthreads();
 
-  // ---- weight stream: forward image then backward image, 2 * bf_ns chunks per step, three chunks in flight -----
-  const int NS = 2 * a.bf_ns;
-  const char* img = (const char*)a.ws_bf16 + wave * 4096 + lane * 16;
+  // ---- weight stream: forward image then backward image (phase 0: 2 * bf_ns chunks per step; phase 1 the forward half,
+  //      phase 2 the backward half only), three chunks in flight -----
+  const int NS = (PHASE == 0 ? 2 : 1) * a.bf_ns;
+  const char* img = (const char*)a.ws_bf16 + (PHASE == 2 ? (size_t)a.bf_ns * BF_CHUNK_BYTES : 0) + wave * 4096 + lane * 16;
   auto issue = [&](int seq, unsigned boff) {
     const char* src = img + (size_t)seq * BF_CHUNK_BYTES;
     char* dst = smem + boff + wave * 4096;
     sfor<4>([&](auto II) { constexpr int i = decltype(II)::value; dma16_bf<i * 1024>(src, dst); });
   };
   issue(0, 0);
-  issue(1, BF_CHUNK_BYTES);
-  issue(2, 2 * BF_CHUNK_BYTES);
-  int seq_issue = 3;                                      // NS >= 4 always (L >= 1: 2 * (1 + 4 (L - 1) + 1))
+  issue(1 % NS, BF_CHUNK_BYTES);
+  issue(2 % NS, 2 * BF_CHUNK_BYTES);
+  int seq_issue = 3 % NS;                                 // NS >= 2 (L = 1, one phase: 1 + 0 + 1 chunks)
   unsigned boff_issue = 3 * BF_CHUNK_BYTES, boff_cur = 0;
-  // vmcnt(8): everything but the newest 8 vector-memory operations has completed.  The two newer chunks are 8 DMAs
-  // of this wave; stash stores / loads issued since only make the wait stricter than needed (memory operations
-  // complete in issue order), never weaker.
+  // The chunk about to be consumed was issued three calls ago; everything issued after its 4 DMAs may stay in flight:
+  // the 8 DMAs of the two newer chunks plus the stash stores / loads of the three intervals since (vm0..vm2, counted by the
+  // layer epilogues; memory operations complete in issue order).  A plain vmcnt(8) would make every chunk boundary wait for
+  // the stash traffic AND, through it, for the newer chunks' DMAs — the prefetch would never run ahead.  Uncounted
+  // operations (history, noise, dL/deps) only make the wait stricter than needed, never weaker.
+  int vm0 = 0, vm1 = 0, vm2 = 0;
   auto next_chunk = [&]() -> const char* {
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    const int n = 8 + vm0 + vm1 + vm2;
+    if (n >= 56) asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
+    else if (n >= 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+    else if (n >= 40) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+    else if (n >= 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    vm2 = vm1; vm1 = vm0; vm0 = 0;
     __builtin_amdgcn_s_barrier();
     issue(seq_issue, boff_issue);
     seq_issue = (seq_issue + 1 == NS) ? 0 : seq_issue + 1;
@@ -202,8 +230,8 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
     const bool valid = chain < a.B;
     const long long state = (a.particles == 1) ? chain : chain / a.particles;
 
-    u32x4 cbp[CKS];     // cond operands, packed once per tile
-    sfor<CKS>([&](auto CI) {
+    u32x4 cbp[CKS];     // cond operands, packed once per tile (the stash backward never contracts them)
+    if constexpr (PHASE != 2) sfor<CKS>([&](auto CI) {
       constexpr int kc = decltype(CI)::value;
       float cv[8];
       sfor<8>([&](auto EI) {
@@ -214,31 +242,35 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
       sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; cbp[kc][w] = pack2(cv[2 * w], cv[2 * w + 1]); });
     });
     float gx[NRX];      // dL/dx_{j+1}: register r <-> action row ROWR(r) + 4 s, like the chain state
+    float xs[NRX];      // phase 1: the chain state; phases 0 / 2: x_j from the history
     sfor<NRX>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
       const int ai = BF_ROWR(r) + 4 * ls;
-      gx[r] = (valid && ai < a.A) ? b.g_x0[chain * a.A + ai] : 0.0f;
+      if constexpr (PHASE == 1) { xs[r] = (valid && ai < a.A) ? a.xT[chain * a.A + ai] : 0.0f; gx[r] = 0.0f; }
+      else gx[r] = (valid && ai < a.A) ? b.g_x0[chain * a.A + ai] : 0.0f;
     });
 
     for (int jj = 0; jj < a.T; ++jj) {
-      const int j = a.T - 1 - jj;
+      const int j = (PHASE == 1) ? jj : a.T - 1 - jj;
       const long long ts = wt * a.T + j;
       const size_t srow = (size_t)ts * a.L * 4096;          // floats: 16 KB per layer
       const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 16384, 0x00020000);
 
-      float xs[NRX];
-      sfor<NRX>([&](auto RI) {
-        constexpr int r = decltype(RI)::value;
-        const int ai = BF_ROWR(r) + 4 * ls;
-        xs[r] = (valid && ai < a.A) ? b.xt_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
-      });
+      if constexpr (PHASE != 1) {
+        sfor<NRX>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int ai = BF_ROWR(r) + 4 * ls;
+          xs[r] = (valid && ai < a.A) ? b.xt_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        });
+      }
 
       // epilogue of a forward block: h = act(z), act'(z) -> packed bf16, both stashed; h is the next B operand
       auto epi_fwd = [&](u32x4 (&out)[16], int lsoff) {
         char* ph = (char*)(b.hd + srow) + lsoff;
         char* pa = (char*)(b.ad + srow) + lsoff;
-        return [&out, ph, pa, lane16](auto OI, const f32x16& acc) {
+        return [&out, ph, pa, lane16, &vm0](auto OI, const f32x16& acc) {
           constexpr int ob = decltype(OI)::value;
+          vm0 += 4;
           sfor<2>([&](auto QI) {
             constexpr int q = decltype(QI)::value;
             u32x4 hp, dp;
@@ -267,7 +299,15 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
         };
       };
 
-      // ================= forward of step j, recomputed ==========================================================
+      // ================= forward of step j (phase 0: recomputed; phase 1: THE forward; phase 2: read back) ============
+      f32x16 O;
+      if constexpr (PHASE == 2) {
+        sfor<NRX>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int ai = BF_ROWR(r) + 4 * ls;
+          O[r] = (valid && ai < a.A) ? b.eps_hist[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        });
+      } else {
       {
         u32x4 bx;
         sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; bx[w] = pack2(xs[2 * w], xs[2 * w + 1]); });
@@ -282,7 +322,6 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
         layer_g<16, 8>(bh, init_bias(s_bh + (l - 1) * H), epi_fwd(bout, l * 16384), next_chunk, lane16);
         sfor<16>([&](auto KI) { constexpr int k = decltype(KI)::value; bin[k] = bout[k]; });
       }
-      f32x16 O;
       {
         auto bh = [&](auto KI) -> u32x4 { return bin[decltype(KI)::value]; };
         auto init_o = [&](auto, f32x16& acc) {
@@ -291,6 +330,53 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
         auto epi_o = [&](auto, const f32x16& acc) { O = acc; };
         layer_g<16, 1>(bh, init_o, epi_o, next_chunk, lane16);
       }
+      }   // PHASE != 2
+
+      if constexpr (PHASE == 1) {
+        // ================= the sampler's update (the epilogue of csrc/sampler_bf16.hip, f32) ==========================
+        const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
+        const float c2 = s_coef[j * COEF_STRIDE + 2], c3 = s_coef[j * COEF_STRIDE + 3];
+        const float c4 = s_coef[j * COEF_STRIDE + 4], c5 = s_coef[j * COEF_STRIDE + 5];
+        sfor<NRX>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int ai = BF_ROWR(r) + 4 * ls;
+          const bool in = valid && ai < a.A;
+          const float eps = O[r], xt = xs[r];
+          float z = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+          if (a.rng_impl != FRL_RNG_NONE && in && c5 != 0.0f) {
+            z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (in) {
+            const long long o = ((long long)j * a.B + chain) * a.A + ai;
+            a.xt_hist[o] = xt;
+            a.eps_hist[o] = eps;
+          }
+          float xn;
+          if (a.mode == MODE_DDPM_DDPM) {
+            float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
+            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);   // ddpm.py:200-201
+            xn = c2 * (c3 * x0h + c4 * xt);                           // ddpm.py:202-203
+            xn += c5 * z;                                             // ddpm.py:206
+          } else if (a.mode == MODE_DDPM_DDIM) {
+            xn = c0 * (xt - c1 * eps) + c2 * eps;                     // ddpm.py:211
+            if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+          } else if (a.mode == MODE_CDDPM_DDPM) {
+            float x0h = (xt - c1 * eps) / c0;                         // continuous_ddpm.py:165
+            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+            xn = c2 * x0h + c3 * xt;                                  // :173
+            xn += c5 * z;                                             // :174
+          } else if (a.mode == MODE_CDDPM_DDIM) {
+            float x0h = (xt - c1 * eps) / c0;
+            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
+            xn = c2 * x0h + c3 * eps;                                 // :177
+          } else {
+            xn = xt + eps / c0;                                       // cnf.py:108
+            if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
+          }
+          xs[r] = in ? xn : 0.0f;
+        });
+      } else {
 
       // ================= VJP of the update: dL/deps and the direct part of dL/dx_j ===============================
       const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
@@ -336,8 +422,9 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
       // next B operand, stashed as the G operand of the weight gradients
       u32x4 dpre[2][2];
       auto init_bwd = [&](int lsoff) {
-        return [&dpre, lsoff, &rs_ad, lane16](auto OI, f32x16& acc) {
+        return [&dpre, lsoff, &rs_ad, lane16, &vm0](auto OI, f32x16& acc) {
           constexpr int ob = decltype(OI)::value;
+          vm0 += 2;
           sfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; acc[r] = 0.0f; });
           dpre[ob & 1][0] = ld16(rs_ad, lane16, lsoff + (2 * ob) * 1024);
           dpre[ob & 1][1] = ld16(rs_ad, lane16, lsoff + (2 * ob + 1) * 1024);
@@ -345,8 +432,9 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
       };
       auto epi_bwd = [&](u32x4 (&out)[16], int lsoff) {
         char* pg = (char*)(b.gd + srow) + lsoff;
-        return [&out, &dpre, pg, lane16](auto OI, const f32x16& acc) {
+        return [&out, &dpre, pg, lane16, &vm0](auto OI, const f32x16& acc) {
           constexpr int ob = decltype(OI)::value;
+          vm0 += 2;
           sfor<2>([&](auto QI) {
             constexpr int q = decltype(QI)::value;
             u32x4 gp;
@@ -381,8 +469,15 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
         const int ai = BF_ROWR(r) + 4 * ls;
         gx[r] = (valid && ai < a.A) ? gxd[r] + OX[r] : 0.0f;
       });
+      }   // PHASE != 1
     }
-    if (b.g_xT != nullptr) {
+    if constexpr (PHASE == 1) {
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = BF_ROWR(r) + 4 * ls;
+        if (valid && ai < a.A) a.x0[chain * a.A + ai] = xs[r];
+      });
+    } else if (b.g_xT != nullptr) {
       sfor<NRX>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
         const int ai = BF_ROWR(r) + 4 * ls;
@@ -395,6 +490,7 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
   __builtin_amdgcn_s_barrier();
 }
 
+#if FRL_BWD16_PHASE == 0
 // ---- weight gradients ---------------------------------------------------------------------------------------------
 constexpr int DW_ROWB = 80;                    // bytes per LDS feature row: 32 chains x bf16 + 16 pad (conflict-free b128 reads)
 constexpr int DW_TILE = 256 * DW_ROWB;         // one operand tile
@@ -574,10 +670,22 @@ frl_bwd_dw_bf16_kernel(const BArgs b) {
   dw_layer<DW_LAST>(b, a.L, smem_dw16, u0, u1, n_wtv);
 }
 
+int launch_bwd_dw_bf16(const BArgs& b, hipStream_t stream) {
+  const int g2 = b.n_part;                                // one partial slot per workgroup (BwdPlan16.n_part)
+  const size_t lds2 = 4 * (size_t)DW_TILE;
+  hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  hipLaunchKernelGGL(frl_bwd_dw_bf16_kernel, dim3(g2), dim3(512), lds2, stream, b);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("bf16 bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return launch_bwd_reduce(b, stream);
+}
+#endif  // FRL_BWD16_PHASE == 0
+
 // ---- launcher -----------------------------------------------------------------------------------------------------
 template <int ACT>
 static int launch_sweep16(const BArgs& b, int grid, size_t lds, hipStream_t stream) {
-  auto kern = frl_bwd_sweep_bf16_kernel<ACT>;
+  auto kern = frl_bwd_sweep_bf16_kernel<ACT, FRL_BWD16_PHASE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, b);
@@ -586,7 +694,8 @@ static int launch_sweep16(const BArgs& b, int grid, size_t lds, hipStream_t stre
   return FRL_OK;
 }
 
-int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
+template <>
+int launch_bwd16_sweep_phase<FRL_BWD16_PHASE>(const FrlDesc& d, const BArgs& b, hipStream_t stream) {
   const KArgs& a = b.k;
   int dev = 0, ncu = 256;
   (void)hipGetDevice(&dev);
@@ -603,15 +712,17 @@ int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& b, hipStream_t stream
     case FRL_ACT_RELU: rc = launch_sweep16<FRL_ACT_RELU>(b, grid, lds, stream); break;
     default: set_error("bf16 bwd: activation %d has no VJP kernel (mish / silu / relu)", d.act); return FRL_EUNSUPPORTED;
   }
-  if (rc != FRL_OK) return rc;
-  const int g2 = b.n_part;                                // one partial slot per workgroup (BwdPlan16.n_part)
-  const size_t lds2 = 4 * (size_t)DW_TILE;
-  hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
-  hipLaunchKernelGGL(frl_bwd_dw_bf16_kernel, dim3(g2), dim3(512), lds2, stream, b);
-  e = hipGetLastError();
-  if (e != hipSuccess) { set_error("bf16 bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
-  return launch_bwd_reduce(b, stream);
+  return rc;
 }
+
+#if FRL_BWD16_PHASE == 0
+// phase 0: recompute + backward; 1: training forward (no gradients yet); 2: backward from the stash
+int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& b, int phase, hipStream_t stream) {
+  int rc = phase == 0 ? launch_bwd16_sweep_phase<0>(d, b, stream) : phase == 1 ? launch_bwd16_sweep_phase<1>(d, b, stream)
+                                                                                 : launch_bwd16_sweep_phase<2>(d, b, stream);
+  if (rc != FRL_OK || phase == 1) return rc;
+  return launch_bwd_dw_bf16(b, stream);
+}
+#endif
 
 }  // namespace frl

@@ -368,7 +368,7 @@ class VjpContext:
 def run_sampler_train(network, params: Dict, *, kind: int, solver: int, steps: int, xT: torch.Tensor,
                       condition: Optional[torch.Tensor], noise: Optional[torch.Tensor], sched: Dict[str, torch.Tensor],
                       clip_sampler: bool, x_min, x_max, particles: Optional[int] = None, rng_key: Optional[torch.Tensor] = None,
-                      rng_impl: Optional[str] = None, rng_shard: Optional[Tuple[int, int]] = None):
+                      rng_impl: Optional[str] = None, rng_shard: Optional[Tuple[int, int]] = None, compute_dtype: str = "f32"):
     """sample(training=True, params=p) for a caller that will differentiate through the chain (dql.py:105-112): one
     launch of the training-forward kernel, which is the sampler plus the stash the backward sweep reads instead of
     recomputing.  Returns (x0, (xt_hist, eps_hist), ctx[, rng_out]); pass ``ctx`` to :func:`run_sampler_vjp`."""
@@ -380,7 +380,7 @@ def run_sampler_train(network, params: Dict, *, kind: int, solver: int, steps: i
     lead = tuple(xT.shape[:-1])
     desc, fparams, fs, keep, B, cond2d = _marshal(
         network, params, kind=kind, solver=solver, steps=steps, xT=xT, condition=condition, sched=sched,
-        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles,
+        clip_sampler=clip_sampler, x_min=x_min, x_max=x_max, history=True, particles=particles, compute_dtype=compute_dtype,
         rng_impl=0 if rng_key is None else _random.impl_id(rng_impl))
     need = lib.frl_bwd_workspace_bytes(C.byref(desc))
     if need == 0:

@@ -95,13 +95,11 @@ class ContinuousDDPM:
             noise = draw_noise(rng, (steps, *xT.shape), xT.device)
         sched = self._device_tables(steps, t_schedule_n, solver == "dpm2", dev)
         if keep_for_vjp:
-            if compute_dtype != "f32":
-                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "keep_for_vjp: the training forward is f32 (bf16: sample(history=True) + sample_vjp, which recomputes)")
             tout = run_sampler_train(
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
-            particles=particles, rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
+            particles=particles, compute_dtype=compute_dtype, rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
             return (tout[3] if key is not None else rng), tout[0], (tout[1][0], tout[1][1], tout[2])
         out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],

@@ -84,15 +84,13 @@ class DDPM:
         if solver == "ddpm" and noise is None and key is None:
             noise = draw_noise(rng, (self.steps, *xT.shape), xT.device)
         if keep_for_vjp:
-            if compute_dtype != "f32":
-                raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "keep_for_vjp: the training forward is f32 (bf16: sample(history=True) + sample_vjp, which recomputes)")
             tout = run_sampler_train(
             self.network, p, kind=_lib.FRL_KIND_DDPM,
             solver=_lib.FRL_SOLVER_DDPM if solver == "ddpm" else _lib.FRL_SOLVER_DDIM,
             steps=self.steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max,
-            particles=particles, rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
+            particles=particles, compute_dtype=compute_dtype, rng_key=key, rng_impl=rng_impl, rng_shard=rng_shard)
             return (tout[3] if key is not None else rng), tout[0], (tout[1][0], tout[1][1], tout[2])
         out = run_sampler(
             self.network, p, kind=_lib.FRL_KIND_DDPM,

@@ -57,14 +57,14 @@ def _oracle(case, params, xT, cond, noise, g, xt_hist=None):
     return out
 
 
-def _run(case):
+def _run(case, stash=False):
     import torch
     from test_gpu_vjp import product_vjp
     assert case.bf16
     params, xT, cond, noise = H.make_inputs(case)
     g = np.random.default_rng(77 + case.seed).standard_normal((case.B, case.A)).astype(np.float32)
     model = H.product_model(case, params)
-    grads, gxT, xh = product_vjp(case, model, xT, cond, noise, g, compute_dtype="bf16")
+    grads, gxT, xh = product_vjp(case, model, xT, cond, noise, g, compute_dtype="bf16", stash=stash)
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in _flatten(grads).items()}
     got["dL/dxT"] = gxT.cpu().numpy()
@@ -108,6 +108,34 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
 def test_vjp_bf16(case):
     _run(case)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
+def test_vjp_bf16_training_forward_stash(case):
+    """The same bars with the bf16 TRAINING forward (frl_sampler_fwd_train, dtype bf16: the sampler + the stash of
+    act(z) / act'(z)) and the backward from that stash (have_stash: no forward MFMAs, no activation VALU in the sweep)."""
+    _run(case, stash=True)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[10], CASES[11]], ids=lambda c: c.name)
+def test_bf16_training_forward_is_the_sampler(case):
+    """frl_sampler_fwd_train(bf16) returns bit for bit what the plain bf16 sampler returns (x0 and both histories), and the
+    stash backward returns bit for bit the gradients of the recompute backward (same dL/dz, same fixed-order reduce)."""
+    import torch
+    from test_gpu_vjp import product_vjp
+    params, xT, cond, noise = H.make_inputs(case)
+    g = np.random.default_rng(5).standard_normal((case.B, case.A)).astype(np.float32)
+    model = H.product_model(case, params)
+    a, b = {}, {}
+    g0, gx0, _ = product_vjp(case, model, xT, cond, noise, g, compute_dtype="bf16", stash=False, out=a)
+    g1, gx1, _ = product_vjp(case, model, xT, cond, noise, g, compute_dtype="bf16", stash=True, out=b)
+    torch.cuda.synchronize()
+    for k in ("x0", "xt_hist", "eps_hist"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(gx0, gx1)
+    f0, f1 = _flatten(g0), _flatten(g1)
+    for k in f0:
+        assert torch.equal(f0[k], f1[k]), k
 
 
 def test_vjp_bf16_unsupported_is_loud():
