@@ -291,7 +291,8 @@ int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order seco
 // (same chunk format: W_L^T, transposed hidden kernels top-down, Dense_0's x rows), so that the sweep cycles through
 // 2 * bf_ns chunks per step; then the stash, packed bf16 in the B-operand layout of the sweep
 // ([16 k-step pieces][64 lanes][8 bf16] = 16 KB per (wave-tile, step, layer)):
-//   Hd = bf16(act(z_l)), Ad = bf16(act'(z_l)), Gd = bf16(dL/dz_l), and Ge = bf16(dL/deps) (one 1 KB piece).
+//   Zd = bf16(z_l) (one copy: the sweep recomputes act'(z), the dW kernel act(z) from it), Gd = bf16(dL/dz_l), and
+//   Ge = bf16(dL/deps) (one 1 KB piece).
 // Wave tiles are counted per 256-chain workgroup tile (8 each), so that every wave of the sweep owns a stash slot.
 struct BwdPlan16 {
   Plan f;
@@ -308,8 +309,8 @@ inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
   size_t o = p.total_floats;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
   b.off_img_b = take((size_t)p.bf_ns * (BF_CHUNK_BYTES / 4));
-  b.off_hd = take((size_t)b.n_ts * p.L * 4096);
-  b.off_ad = take((size_t)b.n_ts * p.L * 4096);
+  b.off_hd = take((size_t)b.n_ts * p.L * 4096);   // Zd = bf16(z_l): act(z) / act'(z) are recomputed by the consumers
+  b.off_ad = b.off_hd;                            // (no separate act' stash)
   b.off_gd = take((size_t)b.n_ts * p.L * 4096);
   b.off_ge = take((size_t)b.n_ts * 256);
   b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));

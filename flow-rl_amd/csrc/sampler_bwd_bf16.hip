@@ -194,23 +194,13 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
   issue(2 % NS, 2 * BF_CHUNK_BYTES);
   int seq_issue = 3 % NS;                                 // NS >= 2 (L = 1, one phase: 1 + 0 + 1 chunks)
   unsigned boff_issue = 3 * BF_CHUNK_BYTES, boff_cur = 0;
-  // The chunk about to be consumed was issued three calls ago; everything issued after its 4 DMAs may stay in flight:
-  // the 8 DMAs of the two newer chunks plus the stash stores / loads of the three intervals since (vm0..vm2, counted by the
-  // layer epilogues; memory operations complete in issue order).  A plain vmcnt(8) would make every chunk boundary wait for
-  // the stash traffic AND, through it, for the newer chunks' DMAs — the prefetch would never run ahead.  Uncounted
-  // operations (history, noise, dL/deps) only make the wait stricter than needed, never weaker.
-  int vm0 = 0, vm1 = 0, vm2 = 0;
+  // vmcnt(8): at most the newest 8 vector-memory operations are still in flight.  Loads complete in issue order among
+  // themselves, and the two newer chunks are 8 DMA loads of this wave, so the chunk about to be read has landed whatever the
+  // stash stores do (stores are NOT ordered against loads on this chip: counting them into a larger vmcnt — tried in round 2 —
+  // lets a wave pass with its own DMA still in flight; the relu VJP case caught it).  Stash traffic issued since only makes
+  // the wait stricter than needed.
   auto next_chunk = [&]() -> const char* {
-    const int n = 8 + vm0 + vm1 + vm2;
-    if (n >= 56) asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)" ::: "memory");
-    else if (n >= 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
-    else if (n >= 40) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
-    else if (n >= 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
-    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    vm2 = vm1; vm1 = vm0; vm0 = 0;
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(seq_issue, boff_issue);
     seq_issue = (seq_issue + 1 == NS) ? 0 : seq_issue + 1;
@@ -254,7 +244,7 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
       const int j = (PHASE == 1) ? jj : a.T - 1 - jj;
       const long long ts = wt * a.T + j;
       const size_t srow = (size_t)ts * a.L * 4096;          // floats: 16 KB per layer
-      const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 16384, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.hd + srow), 0, a.L * 16384, 0x00020000);   // the stashed z
 
       if constexpr (PHASE != 1) {
         sfor<NRX>([&](auto RI) {
@@ -264,27 +254,25 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
         });
       }
 
-      // epilogue of a forward block: h = act(z), act'(z) -> packed bf16, both stashed; h is the next B operand
+      // epilogue of a forward block: z packed to bf16 and stashed ONCE (the consumers recompute act(z) / act'(z) from it:
+      // half the stash bytes of keeping h and act'); h = act(z) from the f32 z is the next B operand
       auto epi_fwd = [&](u32x4 (&out)[16], int lsoff) {
-        char* ph = (char*)(b.hd + srow) + lsoff;
-        char* pa = (char*)(b.ad + srow) + lsoff;
-        return [&out, ph, pa, lane16, &vm0](auto OI, const f32x16& acc) {
+        char* pz = (char*)(b.hd + srow) + lsoff;
+        return [&out, pz, lane16](auto OI, const f32x16& acc) {
           constexpr int ob = decltype(OI)::value;
-          vm0 += 4;
           sfor<2>([&](auto QI) {
             constexpr int q = decltype(QI)::value;
-            u32x4 hp, dp;
+            u32x4 hp, zp;
             sfor<4>([&](auto WI) {
               constexpr int w = decltype(WI)::value;
               float h0, d0, h1, d1;
               act_grad_bf<ACT>(acc[8 * q + 2 * w], h0, d0);
               act_grad_bf<ACT>(acc[8 * q + 2 * w + 1], h1, d1);
               hp[w] = pack2(h0, h1);
-              dp[w] = pack2(d0, d1);
+              zp[w] = pack2(acc[8 * q + 2 * w], acc[8 * q + 2 * w + 1]);
             });
             out[2 * ob + q] = hp;
-            st16(hp, ph, lane16, (2 * ob + q) * 1024);
-            st16(dp, pa, lane16, (2 * ob + q) * 1024);
+            st16(zp, pz, lane16, (2 * ob + q) * 1024);
           });
         };
       };
@@ -418,13 +406,12 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
       *(u32x4*)((char*)b.ge + (size_t)ts * 1024 + lane16) = gep;
 
       // ================= backward through the net ================================================================
-      // epilogue of a backward block: dL/dz = dL/dh * act'(z) (act' from the stash, fetched by init), packed = the
-      // next B operand, stashed as the G operand of the weight gradients
+      // epilogue of a backward block: dL/dz = dL/dh * act'(z) (act' recomputed in f32 from the stashed bf16 z, fetched by
+      // init), packed = the next B operand, stashed as the G operand of the weight gradients
       u32x4 dpre[2][2];
       auto init_bwd = [&](int lsoff) {
-        return [&dpre, lsoff, &rs_ad, lane16, &vm0](auto OI, f32x16& acc) {
+        return [&dpre, lsoff, &rs_ad, lane16](auto OI, f32x16& acc) {
           constexpr int ob = decltype(OI)::value;
-          vm0 += 2;
           sfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; acc[r] = 0.0f; });
           dpre[ob & 1][0] = ld16(rs_ad, lane16, lsoff + (2 * ob) * 1024);
           dpre[ob & 1][1] = ld16(rs_ad, lane16, lsoff + (2 * ob + 1) * 1024);
@@ -432,16 +419,18 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
       };
       auto epi_bwd = [&](u32x4 (&out)[16], int lsoff) {
         char* pg = (char*)(b.gd + srow) + lsoff;
-        return [&out, &dpre, pg, lane16, &vm0](auto OI, const f32x16& acc) {
+        return [&out, &dpre, pg, lane16](auto OI, const f32x16& acc) {
           constexpr int ob = decltype(OI)::value;
-          vm0 += 2;
           sfor<2>([&](auto QI) {
             constexpr int q = decltype(QI)::value;
             u32x4 gp;
             sfor<4>([&](auto WI) {
               constexpr int w = decltype(WI)::value;
-              const unsigned dw = dpre[ob & 1][q][w];
-              gp[w] = pack2(acc[8 * q + 2 * w] * bf_lo(dw), acc[8 * q + 2 * w + 1] * bf_hi(dw));
+              const unsigned zw = dpre[ob & 1][q][w];
+              float h0, d0, h1, d1;
+              act_grad_bf<ACT>(bf_lo(zw), h0, d0);
+              act_grad_bf<ACT>(bf_hi(zw), h1, d1);
+              gp[w] = pack2(acc[8 * q + 2 * w] * d0, acc[8 * q + 2 * w + 1] * d1);
             });
             out[2 * ob + q] = gp;
             st16(gp, pg, lane16, (2 * ob + q) * 1024);
@@ -507,7 +496,21 @@ __device__ __forceinline__ void lds_put_piece(char* tile, int ks, int li, int ls
   });
 }
 
-template <int KIND>
+// h = act(z) of a stashed piece (8 bf16 z per lane), re-packed: the X operand of the next layer's weight gradient
+template <int ACT>
+__device__ __forceinline__ u32x4 act_piece(u32x4 z) {
+  u32x4 o;
+  sfor<4>([&](auto WI) {
+    constexpr int w = decltype(WI)::value;
+    float h0, d0, h1, d1;
+    act_grad_bf<ACT>(bf_lo(z[w]), h0, d0);
+    act_grad_bf<ACT>(bf_hi(z[w]), h1, d1);
+    o[w] = pack2(h0, h1);
+  });
+  return o;
+}
+
+template <int KIND, int ACT>
 __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, long long u0, long long u1, long long n_wtv) {
   const KArgs& a = b.k;
   constexpr int H = 256;
@@ -536,11 +539,14 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
     }
   }
 
-  // staging registers of one tile-step
-  u32x4 xr[2], gr[2];
-  float xv[2];
+  // staging registers of TWO tile-steps in flight (sets 0 / 1 by the parity of u - u0): the loads of tile-step u + 3 are
+  // issued when tile-step u + 1 is staged, two iterations (~ 2 x (16 MFMAs + transposes)) before they are needed — one
+  // iteration ahead left most of the HBM latency exposed (round 2: 0.93 ms at 4.2 TB/s)
+  u32x4 xr[2][2], gr[2][2];
+  float xv[2][2];
   auto unit = [&](long long u, long long& ts, int& j, long long& wt) { j = (int)(u / n_wtv); wt = u - (long long)j * n_wtv; ts = wt * T + j; };
-  auto fetch = [&](long long u) {
+  auto fetch = [&](long long u, auto SI) {
+    constexpr int st = decltype(SI)::value;
     long long ts, wt; int j;
     unit(u, ts, j, wt);
     if constexpr (KIND == DW_FIRST) {
@@ -553,50 +559,55 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
           if (row < A) v = b.xt_hist[((long long)j * a.B + chain) * A + row];
           else if (row < A + C) v = a.cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
         }
-        xv[k] = v;
+        xv[st][k] = v;
       });
     } else {
       const char* src = (const char*)b.hd + ((size_t)ts * L + (lam - 1)) * 16384 + lane * 16;
-      xr[0] = *(const u32x4*)(src + wave * 1024);
-      xr[1] = *(const u32x4*)(src + (wave + 8) * 1024);
+      xr[st][0] = *(const u32x4*)(src + wave * 1024);
+      xr[st][1] = *(const u32x4*)(src + (wave + 8) * 1024);
     }
     if constexpr (KIND == DW_LAST) {
-      if (wave == 0) gr[0] = *(const u32x4*)((const char*)b.ge + (size_t)ts * 1024 + lane * 16);
+      if (wave == 0) gr[st][0] = *(const u32x4*)((const char*)b.ge + (size_t)ts * 1024 + lane * 16);
     } else {
       const char* src = (const char*)b.gd + ((size_t)ts * L + lam) * 16384 + lane * 16;
-      gr[0] = *(const u32x4*)(src + wave * 1024);
-      gr[1] = *(const u32x4*)(src + (wave + 8) * 1024);
+      gr[st][0] = *(const u32x4*)(src + wave * 1024);
+      gr[st][1] = *(const u32x4*)(src + (wave + 8) * 1024);
     }
   };
-  auto stage = [&](char* buf) {
+  auto stage = [&](char* buf, auto SI) {
+    constexpr int st = decltype(SI)::value;
     char* sX = buf;
     char* sG = buf + DW_TILE;
     if constexpr (KIND == DW_FIRST) {
       sfor<2>([&](auto EI) {
         constexpr int k = decltype(EI)::value;
         const int idx = tid + 512 * k, row = idx >> 5, c = idx & 31;
-        *(unsigned short*)(sX + row * DW_ROWB + c * 2) = (unsigned short)(pack2(xv[k], 0.0f) & 0xffffu);
+        *(unsigned short*)(sX + row * DW_ROWB + c * 2) = (unsigned short)(pack2(xv[st][k], 0.0f) & 0xffffu);
       });
     } else {
-      lds_put_piece(sX, wave, li, lh, xr[0]);
-      lds_put_piece(sX, wave + 8, li, lh, xr[1]);
+      lds_put_piece(sX, wave, li, lh, act_piece<ACT>(xr[st][0]));
+      lds_put_piece(sX, wave + 8, li, lh, act_piece<ACT>(xr[st][1]));
     }
     if constexpr (KIND == DW_LAST) {
-      if (wave == 0) lds_put_piece(sG, 0, li, lh, gr[0]);
+      if (wave == 0) lds_put_piece(sG, 0, li, lh, gr[st][0]);
     } else {
-      lds_put_piece(sG, wave, li, lh, gr[0]);
-      lds_put_piece(sG, wave + 8, li, lh, gr[1]);
+      lds_put_piece(sG, wave, li, lh, gr[st][0]);
+      lds_put_piece(sG, wave + 8, li, lh, gr[st][1]);
     }
   };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
 
   if (u0 < u1) {
-    fetch(u0);
-    stage(smem);
-    if (u0 + 1 < u1) fetch(u0 + 1);
+    fetch(u0, S0{});
+    stage(smem, S0{});
+    if (u0 + 1 < u1) fetch(u0 + 1, S1{});
+    if (u0 + 2 < u1) fetch(u0 + 2, S0{});
   }
   __syncthreads();
-  for (long long u = u0; u < u1; ++u) {
-    char* buf = smem + (int)((u - u0) & 1) * 2 * DW_TILE;
+  auto body = [&](long long u, auto PI) {
+    constexpr int par = decltype(PI)::value;
+    char* buf = smem + par * 2 * DW_TILE;
     const char* sX = buf;
     const char* sG = buf + DW_TILE;
     // ---- bias gradient: column sums of G ----
@@ -627,12 +638,16 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
       sfor<NM>([&](auto MI) { constexpr int m = decltype(MI)::value; sfor<NN>([&](auto NI) { constexpr int n = decltype(NI)::value;
         acc[m][n] = mfma_bf(av[m], bv[n], acc[m][n]); }); });
     });
-    // ---- next tile-step into the other buffer ----
+    // ---- next tile-step into the other buffer (its loads were issued two iterations ago); then tile-step u + 3's loads ----
     if (u + 1 < u1) {
-      stage(smem + (int)(((u - u0) & 1) ^ 1) * 2 * DW_TILE);
-      if (u + 2 < u1) fetch(u + 2);
+      stage(smem + (par ^ 1) * 2 * DW_TILE, std::integral_constant<int, par ^ 1>{});
+      if (u + 3 < u1) fetch(u + 3, std::integral_constant<int, par ^ 1>{});
     }
     __syncthreads();
+  };
+  for (long long u = u0; u < u1; u += 2) {
+    body(u, S0{});
+    if (u + 1 < u1) body(u + 1, S1{});
   }
 
   // ---- flush: partial tile into this workgroup's slot (plain stores; the second stage adds the slots in order) ----
@@ -658,6 +673,7 @@ __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, lo
   __syncthreads();
 }
 
+template <int ACT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 frl_bwd_dw_bf16_kernel(const BArgs b) {
   extern __shared__ __attribute__((aligned(16))) char smem_dw16[];
@@ -665,18 +681,27 @@ frl_bwd_dw_bf16_kernel(const BArgs b) {
   const long long n_wtv = (a.B + 31) / 32;               // wave tiles that hold chains
   const long long U = n_wtv * a.T;                        // tile-steps, step-major: u = j * n_wtv + wt
   const long long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
-  dw_layer<DW_FIRST>(b, 0, smem_dw16, u0, u1, n_wtv);
-  for (int lam = 1; lam < a.L; ++lam) dw_layer<DW_HIDDEN>(b, lam, smem_dw16, u0, u1, n_wtv);
-  dw_layer<DW_LAST>(b, a.L, smem_dw16, u0, u1, n_wtv);
+  dw_layer<DW_FIRST, ACT>(b, 0, smem_dw16, u0, u1, n_wtv);
+  for (int lam = 1; lam < a.L; ++lam) dw_layer<DW_HIDDEN, ACT>(b, lam, smem_dw16, u0, u1, n_wtv);
+  dw_layer<DW_LAST, ACT>(b, a.L, smem_dw16, u0, u1, n_wtv);
 }
 
-int launch_bwd_dw_bf16(const BArgs& b, hipStream_t stream) {
+template <int ACT>
+static int launch_dw16_inst(const BArgs& b, hipStream_t stream) {
   const int g2 = b.n_part;                                // one partial slot per workgroup (BwdPlan16.n_part)
   const size_t lds2 = 4 * (size_t)DW_TILE;
-  hipError_t e = hipFuncSetAttribute((const void*)frl_bwd_dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  auto kern = frl_bwd_dw_bf16_kernel<ACT>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
-  hipLaunchKernelGGL(frl_bwd_dw_bf16_kernel, dim3(g2), dim3(512), lds2, stream, b);
-  e = hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(g2), dim3(512), lds2, stream, b);
+  return FRL_OK;
+}
+
+int launch_bwd_dw_bf16(const BArgs& b, int act, hipStream_t stream) {
+  int rc = act == FRL_ACT_MISH ? launch_dw16_inst<FRL_ACT_MISH>(b, stream) : act == FRL_ACT_SILU ? launch_dw16_inst<FRL_ACT_SILU>(b, stream)
+                                                                                                  : launch_dw16_inst<FRL_ACT_RELU>(b, stream);
+  if (rc != FRL_OK) return rc;
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return launch_bwd_reduce(b, stream);
 }
@@ -721,7 +746,7 @@ int launch_sampler_bwd_bf16(const FrlDesc& d, const BArgs& b, int phase, hipStre
   int rc = phase == 0 ? launch_bwd16_sweep_phase<0>(d, b, stream) : phase == 1 ? launch_bwd16_sweep_phase<1>(d, b, stream)
                                                                                  : launch_bwd16_sweep_phase<2>(d, b, stream);
   if (rc != FRL_OK || phase == 1) return rc;
-  return launch_bwd_dw_bf16(b, stream);
+  return launch_bwd_dw_bf16(b, d.act, stream);
 }
 #endif
 

@@ -79,8 +79,10 @@ def _mlp_bwd(p, cache, gout, n_hidden, act_name, has_output, grads):
 
 # ---- predictor with bf16 operands (emulation of csrc/sampler_bf16.hip + csrc/sampler_bwd_bf16.hip) ------------
 # Every Dense contraction takes operands rounded to bf16 and sums exactly: layer inputs and kernels in the forward
-# (orc._predictor_bf16), and in the backward dL/dz_l = bf16(dL/dh_l * bf16(act'(z_l))), dL/deps and the transposed
-# kernels.  The time slice of Dense_0 (folded into the f32 bias table by the kernel) and all biases stay exact.
+# (orc._predictor_bf16), and in the backward dL/deps and the transposed kernels.  The kernel stashes z_l ONCE, rounded to
+# bf16, and its consumers recompute from that: dL/dz_l = bf16(dL/dh_l * act'(bf16(z_l))), and the X operand of dW_{l+1} is
+# bf16(act(bf16(z_l))) (the forward itself uses act of the unrounded z).  The time slice of Dense_0 (folded into the f32
+# bias table by the kernel) and all biases stay exact.
 def _pred_fwd_bf16(spec, p, x, tfeat, condition):
     bf = orc.bf16_round
     act = orc.get_activation(spec.activation)
@@ -115,11 +117,14 @@ def _pred_bwd_bf16(spec, cache, gout, grads):
 
     g = bf(gout)
     xin, _, Wb = cache[n]
+    xin = bf(orc.get_activation(spec.activation)(bf(cache[n - 1][1])))
     acc(n, xin, g)
     g = g @ Wb.T
     for i in reversed(range(n)):
         xin, z, Wb = cache[i]
-        g = bf(g * bf(act_grad(spec.activation, z)))
+        g = bf(g * act_grad(spec.activation, bf(z)))
+        if i > 0:      # dW_i's X operand: act of the STASHED (bf16) z_{i-1}
+            xin = bf(orc.get_activation(spec.activation)(bf(cache[i - 1][1])))
         acc(i, xin, g)
         g = g @ Wb.T
     return g
