@@ -234,7 +234,7 @@ int frl_sampler_fwd_static(const FrlDesc* desc, const FrlParams* params, const F
  *     the stash of frl_sampler_fwd_train; x_dim <= 24, <= 128 condition rows and a cond_embedding MLP (DACER / QVPO
  *     humanoid: act 17, obs 376 -> 128) through frl_sampler_fwd_train + have_stash only.
  *   FRL_DTYPE_BF16 (bf16 operands in every contraction, f32 accumulation): x_dim <= 16, x_dim + cond_dim <= 32, no
- *     cond_embedding, recompute path.
+ *     cond_embedding; from xt_hist alone (recompute) or from the stash of a bf16 frl_sampler_fwd_train.
  * Everything else returns FRL_EUNSUPPORTED. */
 typedef struct FrlBwdBufs {
   const float* xt_hist; /* (T, B, A) history[0] of the forward call                                     */
@@ -268,8 +268,9 @@ size_t frl_bwd_workspace_bytes(const FrlDesc* desc);
  * dql.py:105-112): frl_sampler_fwd with desc.want_history = 1 that ALSO keeps, in the backward workspace
  * (frl_bwd_workspace_bytes), what jax.grad keeps of the unrolled scan — act(z) and act'(z) of every layer and step.
  * A following frl_sampler_bwd on the same workspace with bufs.have_stash = 1 and bufs.eps_hist then runs the backward
- * sweep only.  Results (x0, xt_hist, eps_hist) agree with frl_sampler_fwd's to float32 rounding.  f32, the VJP's shape
- * family (see above); FRL_EUNSUPPORTED otherwise — use frl_sampler_fwd + frl_sampler_bwd (which recomputes) there. */
+ * sweep only.  Results (x0, xt_hist, eps_hist) agree with frl_sampler_fwd's to float32 rounding (dtype bf16: bit for bit;
+ * its stash is one bf16 copy of z per layer, from which the backward recomputes act(z) / act'(z)).  The VJP's shape family
+ * (see above) in either dtype; FRL_EUNSUPPORTED otherwise. */
 int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* bufs,
                           void* bwd_workspace, size_t workspace_bytes, void* hip_stream);
 
