@@ -1,5 +1,7 @@
 // XLA-FFI (jax.ffi) registration shim: a thin translation of XLA custom calls onto the plain C ABI
-// (include/flowrl_hip.h).  Handlers: FrlSamplerFwd (noise-tensor or keyed rng-in / rng-out form) and FrlSamplerBwd.
+// (include/flowrl_hip.h).  Handlers: FrlSamplerFwd (noise-tensor or keyed rng-in / rng-out form), FrlSamplerFwdTrain (the
+// same plus the stash workspace as a result: the residual of a jax.custom_vjp) and FrlSamplerBwd (from xt_hist alone, or
+// from that stash).
 //
 // NOT compiled by build.py in this container: jaxlib's headers (xla/ffi/api/ffi.h, found via jax.ffi.include_dir())
 // are absent here and cannot be fetched.  What IS checked here: tests/test_abi.py::test_ffi_shim_compile_smoke runs
@@ -23,9 +25,19 @@
 //   20.. (kernel_i, bias_i) for i = 0..L, then with attr layer_norm = 1 (scale_i, bias_i) for i = 0..L-1
 // results: x0 (B, A); then rng_out (2,) u32 when rng_impl != 0; then xt_hist, eps_hist (T, B, A) when want_history = 1.
 //
-// FrlSamplerBwd operands: 0 xt_hist, 1 cond, 2 g_x0, 3..19 as above, 20.. (kernel_i, bias_i) for i = 0..L.
+// Residual predictors (attr backbone = 1 ResidualMLP / 2 Simba, forward handlers only): operands 20.. are Dense_0 (kernel, bias),
+// Dense_1 (kernel, bias), then per block Dense_0 (kernel, bias), Dense_1 (kernel, bias), LayerNorm_0 (scale, bias) — the
+// LayerNorm pair present when attr layer_norm = 1 or Simba — and for Simba the final LayerNorm_0 (scale, bias).
+//
+// FrlSamplerFwdTrain: FrlSamplerFwd with want_history forced on and ONE more result after eps_hist: the stash workspace, a
+// u8 buffer of frl_bwd_workspace_bytes(desc) bytes (256-byte aligned, as XLA allocates) that the backward consumes.
+//
+// FrlSamplerBwd operands: 0 xt_hist, 1 cond, 2 g_x0, 3..19 as above, 20.. (kernel_i, bias_i) for i = 0..L; with attr
+// have_stash = 1 two more at the end: eps_hist (T, B, A) and the stash workspace of FrlSamplerFwdTrain (u8) — the backward
+// writes its own scratch into that buffer, so the binding DONATES it (input_output_aliases onto the last result).
 // results: g_xT (B, A); (grad_kernel_i, grad_bias_i) for i = 0..L; grad_tb (T, H); then, with attr native_time = 1,
-//          grad MLP_0/Dense_{0,1} kernel, bias and grad time_embedding/kernel (FrlBwdBufs' optional outputs).
+//          grad MLP_0/Dense_{0,1} kernel, bias and grad time_embedding/kernel (FrlBwdBufs' optional outputs); then, with attr
+//          cond_embed = 1, grad cond_embedding/Dense_{0,1} kernel, bias; then, with have_stash = 1, the donated workspace.
 #include <cstdint>
 #include <cstring>
 
@@ -76,7 +88,7 @@ bool Output(const ffi::RemainingRets& rets, size_t i, ffi::DataType want, T** ou
 
 // FrlDesc from the attribute dictionary + operand shapes; FrlParams / FrlSchedule from operands 3.. (shared by both handlers)
 ffi::Error Marshal(const ffi::RemainingArgs& args, const ffi::Dictionary& attrs, int64_t x_dim, int64_t cond_last,
-                   FrlDesc* d, FrlParams* p, FrlSchedule* s) {
+                   FrlDesc* d, FrlParams* p, FrlSchedule* s, size_t trailing = 0) {
   std::memset(d, 0, sizeof(*d));
   std::memset(p, 0, sizeof(*p));
   std::memset(s, 0, sizeof(*s));
@@ -114,9 +126,32 @@ ffi::Error Marshal(const ffi::RemainingArgs& args, const ffi::Dictionary& attrs,
   }
   if (!ok) return Invalid("time / cond-embedding operands (11..19) must be f32");
 
-  const size_t rest = args.size() - kFixedOperands;
+  d->backbone = AttrOr<int32_t>(attrs, "backbone", FRL_BACKBONE_MLP);
+  if (d->backbone != FRL_BACKBONE_MLP) {
+    d->res_multiplier = AttrOr<int32_t>(attrs, "res_multiplier", 4);
+    const bool simba = d->backbone == FRL_BACKBONE_SIMBA, ln = simba || d->layer_norm;
+    const size_t per_block = ln ? 6 : 4, head = 4 + (simba ? 2 : 0);
+    const size_t restb = args.size() - kFixedOperands - trailing;
+    if (args.size() < kFixedOperands + trailing + head + per_block || (restb - head) % per_block != 0) return Invalid("residual predictor operands: Dense_0, Dense_1, blocks, [final LayerNorm]");
+    d->n_hidden = (int32_t)((restb - head) / per_block);
+    if (d->n_hidden > FRL_MAX_HIDDEN) return Invalid("block count outside [1, FRL_MAX_HIDDEN]");
+    size_t o = kFixedOperands;
+    int64_t width = 0;
+    bool okr = true;
+    for (int i = 0; i < 2 && okr; ++i, o += 2)
+      okr = Operand<float>(args, o, ffi::DataType::F32, &p->kernel[i], i == 0 ? &width : nullptr) && Operand<float>(args, o + 1, ffi::DataType::F32, &p->bias[i]);
+    for (int b = 0; b < d->n_hidden && okr; ++b) {
+      d->hidden[b] = (int32_t)width;
+      for (int k = 0; k < 2 && okr; ++k, o += 2)
+        okr = Operand<float>(args, o, ffi::DataType::F32, &p->res_kernel[b][k]) && Operand<float>(args, o + 1, ffi::DataType::F32, &p->res_bias[b][k]);
+      if (ln && okr) { okr = Operand<float>(args, o, ffi::DataType::F32, &p->res_ln_scale[b]) && Operand<float>(args, o + 1, ffi::DataType::F32, &p->res_ln_bias[b]); o += 2; }
+    }
+    if (simba && okr) okr = Operand<float>(args, o, ffi::DataType::F32, &p->final_ln_scale) && Operand<float>(args, o + 1, ffi::DataType::F32, &p->final_ln_bias);
+    return okr ? ffi::Error::Success() : Invalid("residual predictor operands must be f32");
+  }
+  const size_t rest = args.size() - kFixedOperands - trailing;
   const size_t per_hidden = d->layer_norm ? 4 : 2;            // (kernel, bias) [+ (ln scale, ln bias)] per hidden layer
-  if (args.size() < kFixedOperands + 4 || (rest - 2) % per_hidden != 0) return Invalid("layer operands: (kernel_i, bias_i) for i = 0..L [+ LayerNorm rows]");
+  if (args.size() < kFixedOperands + trailing + 4 || (rest - 2) % per_hidden != 0) return Invalid("layer operands: (kernel_i, bias_i) for i = 0..L [+ LayerNorm rows]");
   d->n_hidden = (int32_t)((rest - 2) / per_hidden);
   if (d->n_hidden < 1 || d->n_hidden > FRL_MAX_HIDDEN) return Invalid("hidden layer count outside [1, FRL_MAX_HIDDEN]");
   for (int l = 0; l <= d->n_hidden; ++l) {
@@ -136,8 +171,8 @@ ffi::Error Marshal(const ffi::RemainingArgs& args, const ffi::Dictionary& attrs,
   return ffi::Error::Success();
 }
 
-ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
-                             ffi::RemainingRets rets, ffi::Dictionary attrs) {
+ffi::Error FwdCommon(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args, ffi::RemainingRets rets,
+                     ffi::Dictionary attrs, bool train) {
   if (args.size() < kFixedOperands + 4) return Invalid("FrlSamplerFwd: too few operands");
   FrlDesc d; FrlParams p; FrlSchedule s;
   FrlFwdBufs b;
@@ -147,6 +182,7 @@ ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
     return Invalid("xT / cond must be f32");
   if (b.cond == nullptr) cond_last = 0;
   if (ffi::Error e = Marshal(args, attrs, x_dim, cond_last, &d, &p, &s); e.failure()) return e;
+  if (train) d.want_history = 1;
   size_t out = 0;
   if (!Output<float>(rets, out++, ffi::DataType::F32, &b.x0)) return Invalid("result 0 (x0) must be f32");
   if (d.rng_impl != FRL_RNG_NONE) {          // keyed form: operand 2 is the threefry key, result 1 the advanced key
@@ -157,6 +193,15 @@ ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
   }
   if (d.want_history && (!Output<float>(rets, out, ffi::DataType::F32, &b.xt_hist) || !Output<float>(rets, out + 1, ffi::DataType::F32, &b.eps_hist)))
     return Invalid("want_history = 1: results xt_hist, eps_hist (T, B, A) f32");
+  if (train) {      // the stash workspace is a RESULT: it outlives this call and feeds FrlSamplerBwd (have_stash = 1)
+    uint8_t* stash = nullptr;
+    auto wb = rets.get<ffi::AnyBuffer>(out + 2);
+    if (!Output<uint8_t>(rets, out + 2, ffi::DataType::U8, &stash) || !wb.has_value()) return Invalid("FrlSamplerFwdTrain: last result = stash workspace (u8)");
+    const size_t need = frl_bwd_workspace_bytes(&d);
+    if (need == 0) return FromRc(frl_sampler_fwd_train(&d, &p, &s, &b, nullptr, 0, (void*)stream));   // says why
+    if ((size_t)(*wb)->element_count() < need) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "stash workspace result smaller than frl_bwd_workspace_bytes(desc)");
+    return FromRc(frl_sampler_fwd_train(&d, &p, &s, &b, stash, (size_t)(*wb)->element_count(), (void*)stream));
+  }
   if (frl_validate(&d) != FRL_OK) return FromRc(frl_validate(&d));
   const size_t need = frl_workspace_bytes(&d);
   auto ws = scratch.Allocate(need > 0 ? need : 256, 256);
@@ -164,9 +209,20 @@ ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
   return FromRc(frl_sampler_fwd(&d, &p, &s, &b, *ws, need, (void*)stream));
 }
 
+ffi::Error FrlSamplerFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
+                             ffi::RemainingRets rets, ffi::Dictionary attrs) {
+  return FwdCommon(stream, scratch, args, rets, attrs, false);
+}
+
+ffi::Error FrlSamplerFwdTrainImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
+                                  ffi::RemainingRets rets, ffi::Dictionary attrs) {
+  return FwdCommon(stream, scratch, args, rets, attrs, true);
+}
+
 ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
                              ffi::RemainingRets rets, ffi::Dictionary attrs) {
   if (args.size() < kFixedOperands + 4) return Invalid("FrlSamplerBwd: too few operands");
+  const bool have_stash = AttrOr<int32_t>(attrs, "have_stash", 0) != 0;
   FrlDesc d; FrlParams p; FrlSchedule s;
   FrlBwdBufs b;
   std::memset(&b, 0, sizeof(b));
@@ -175,7 +231,8 @@ ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
       !Operand<float>(args, 2, ffi::DataType::F32, &b.g_x0, &x_dim))
     return Invalid("xt_hist / cond / g_x0 must be f32");
   if (b.cond == nullptr) cond_last = 0;
-  if (ffi::Error e = Marshal(args, attrs, x_dim, cond_last, &d, &p, &s); e.failure()) return e;
+  if (ffi::Error e = Marshal(args, attrs, x_dim, cond_last, &d, &p, &s, have_stash ? 2 : 0); e.failure()) return e;
+  if (d.backbone != FRL_BACKBONE_MLP) return ffi::Error(ffi::ErrorCode::kUnimplemented, "FrlSamplerBwd: residual predictors have no backward kernel");
   d.want_history = 1;
   size_t out = 0;
   if (!Output<float>(rets, out++, ffi::DataType::F32, &b.g_xT)) return Invalid("result 0 (g_xT) must be f32");
@@ -192,8 +249,26 @@ ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
   } else {
     b.grad_bias[0] = nullptr;      // the binding differentiates the time branch itself from grad_tb (jax.vjp)
   }
+  if (d.cond_embed)
+    for (int k = 0; k < 2; ++k)
+      if (!Output<float>(rets, out++, ffi::DataType::F32, &b.grad_cond_kernel[k]) || !Output<float>(rets, out++, ffi::DataType::F32, &b.grad_cond_bias[k]))
+        return Invalid("cond_embed = 1: results grad cond_embedding/Dense_{0,1} kernel, bias");
   const size_t need = frl_bwd_workspace_bytes(&d);
   if (need == 0) return FromRc(frl_sampler_bwd(&d, &p, &s, &b, nullptr, 0, (void*)stream));   // says why
+  if (have_stash) {
+    // operands ... eps_hist, stash workspace; the workspace is donated onto the last result (the backward writes into it)
+    const uint8_t* ws_in = nullptr;
+    uint8_t* ws_out = nullptr;
+    auto wb = rets.get<ffi::AnyBuffer>(out);
+    if (!Operand<float>(args, args.size() - 2, ffi::DataType::F32, &b.eps_hist) || !Operand<uint8_t>(args, args.size() - 1, ffi::DataType::U8, &ws_in) ||
+        !Output<uint8_t>(rets, out, ffi::DataType::U8, &ws_out) || !wb.has_value())
+      return Invalid("have_stash = 1: last operands eps_hist (f32), stash workspace (u8); last result the donated workspace (u8)");
+    if ((size_t)(*wb)->element_count() < need) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "stash workspace smaller than frl_bwd_workspace_bytes(desc)");
+    if (ws_in != ws_out && hipMemcpyAsync(ws_out, ws_in, need, hipMemcpyDeviceToDevice, stream) != hipSuccess)   // not aliased: keep the stash
+      return ffi::Error(ffi::ErrorCode::kInternal, "stash workspace copy failed");
+    b.have_stash = 1;
+    return FromRc(frl_sampler_bwd(&d, &p, &s, &b, ws_out, (size_t)(*wb)->element_count(), (void*)stream));
+  }
   auto ws = scratch.Allocate(need, 256);
   if (!ws.has_value()) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "scratch allocation failed (the VJP stash grows with B * T * L)");
   return FromRc(frl_sampler_bwd(&d, &p, &s, &b, *ws, need, (void*)stream));
@@ -202,6 +277,14 @@ ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
 }  // namespace
 
 XLA_FFI_DEFINE_HANDLER_SYMBOL(FrlSamplerFwd, FrlSamplerFwdImpl,
+                              ffi::Ffi::Bind()
+                                  .Ctx<ffi::PlatformStream<hipStream_t>>()
+                                  .Ctx<ffi::ScratchAllocator>()
+                                  .RemainingArgs()
+                                  .RemainingRets()
+                                  .Attrs());
+
+XLA_FFI_DEFINE_HANDLER_SYMBOL(FrlSamplerFwdTrain, FrlSamplerFwdTrainImpl,
                               ffi::Ffi::Bind()
                                   .Ctx<ffi::PlatformStream<hipStream_t>>()
                                   .Ctx<ffi::ScratchAllocator>()

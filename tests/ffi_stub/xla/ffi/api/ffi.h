@@ -20,7 +20,7 @@ struct XLA_FFI_Error;
 namespace xla::ffi {
 
 enum class ErrorCode { kOk, kInvalidArgument, kUnimplemented, kResourceExhausted, kInternal };
-enum class DataType { F32, U32, S32, BF16 };
+enum class DataType { F32, U32, S32, BF16, U8 };
 
 class Error {
  public:

@@ -142,5 +142,5 @@ def test_ffi_shim_compile_smoke():
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
     src = (root / "flow-rl_amd" / "csrc" / "xla_ffi_shim.cc").read_text()
-    for sym in ("FrlSamplerFwd", "FrlSamplerBwd", "frl_sampler_fwd(", "frl_sampler_bwd(", "rng_impl", "cond_embed", "layer_norm", "dtype"):
+    for sym in ("FrlSamplerFwd", "FrlSamplerFwdTrain", "FrlSamplerBwd", "frl_sampler_fwd(", "frl_sampler_fwd_train(", "frl_sampler_bwd(", "rng_impl", "cond_embed", "layer_norm", "dtype", "backbone", "have_stash"):
         assert sym in src, sym
