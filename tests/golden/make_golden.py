@@ -26,6 +26,13 @@ BIG_CASES = [
     H.Case("golden_cfg4_dacer_embed", "cddpm", A=17, S=376, T=20, B=4 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
            cond_embed=True, seed=106),
 ]
+# residual predictors: 1 .. 4 MB of block kernels each -> seed + SHA-256, as cfg3
+RES_CASES = [
+    H.Case("golden_res_dac_resnet", "ddpm", A=3, S=11, T=5, B=24, hidden=(256, 256), backbone="residual", ln=True, seed=109),
+    H.Case("golden_simba_cnf", "cnf", A=6, S=17, T=10, B=24, hidden=(256,), backbone="simba", act="relu", seed=110),
+]
+# the evaluation under jax.grad (frl_net_eval_train / frl_net_eval_bwd): per-sample time, every gradient leaf
+EVAL_VJP_CASE = H.Case("golden_eval_vjp", "cddpm", A=6, S=17, T=20, B=40, temb="learnable_fourier", schedule="cosine", act="silu", seed=111)
 VJP_CASE = H.Case("golden_cfg5_vjp", "ddpm", A=3, S=11, T=5, B=40, seed=107)
 CRITIC = dict(name="golden_critic_select", B=12, N=10, S=11, A=3, hidden=(256, 256, 256), act="mish", E=2, seed=108)
 
@@ -57,11 +64,11 @@ def main():
         flat = {"p:" + k: v for k, v in orc.flatten_tree(params).items()}
         np.savez_compressed(out / f"{c.name}.npz", xT=xT, cond=cond, noise=noise, x0=x0, xt_hist=xh, eps_hist=eh, **flat)
         print(c.name, x0.shape, float(np.abs(x0).max()))
-    for c in BIG_CASES:
+    for c in BIG_CASES + RES_CASES:
         params, xT, cond, noise = H.make_inputs(c)
         x0, xh, eh = H.oracle_run(c, params, xT, cond, noise, dtype=np.float64)
         keep = dict(xT=xT, cond=cond, noise=noise, x0=x0, xt_hist=xh, eps_hist=eh)
-        if c.hidden[0] == 512:
+        if c.hidden[0] == 512 or c.backbone != "mlp":
             keep.update(params_sha256=np.array(params_digest(params)), params_seed=np.array(c.seed))
         else:
             keep.update({"p:" + k: v for k, v in orc.flatten_tree(params).items()})
@@ -75,6 +82,21 @@ def main():
     g = np.random.default_rng(77 + c.seed).standard_normal((c.B, c.A)).astype(np.float32)
     x0, gref, gx = oracle_vjp(c, params, xT, cond, noise, g)
     np.savez_compressed(out / f"{c.name}.npz", xT=xT, cond=cond, noise=noise, g=g, x0=x0, g_xT=gx,
+                        **{"p:" + k: v for k, v in orc.flatten_tree(params).items()},
+                        **{"g:" + k: v for k, v in _flatten(gref).items()})
+    print(c.name, len(_flatten(gref)), "leaves")
+    # single-evaluation VJP: per-sample t, cotangent in, every leaf + dL/dx out
+    import flowrl_oracle_vjp as ov
+    c = EVAL_VJP_CASE
+    params, x, cond, _ = H.make_inputs(c)
+    rng = np.random.default_rng(150 + c.seed)
+    t = rng.uniform(1e-3, 0.9946, size=(c.B, 1)).astype(np.float32)
+    g = rng.standard_normal((c.B, c.A)).astype(np.float32)
+    p64 = orc.cast_tree(params, np.float64)
+    ev_out, cache = ov.backbone_fwd(c.spec, p64, x.astype(np.float64), t.astype(np.float64), cond.astype(np.float64))
+    gref: dict = {}
+    gx = ov.backbone_bwd(c.spec, p64, cache, g.astype(np.float64), gref)
+    np.savez_compressed(Path(__file__).resolve().parent / f"{c.name}.npz", x=x, cond=cond, t=t, g=g, out=ev_out, g_x=gx,
                         **{"p:" + k: v for k, v in orc.flatten_tree(params).items()},
                         **{"g:" + k: v for k, v in _flatten(gref).items()})
     print(c.name, len(_flatten(gref)), "leaves")

@@ -92,3 +92,19 @@ def test_residual_refusals():
         model.sample(None, x, c, noise=nz, tile_policy="latency")
     with pytest.raises(_lib.FlowRLHipUnsupported):
         model.sample(None, x, c, True, noise=nz, history=True, keep_for_vjp=True, params=model.params)
+
+
+def test_residual_against_committed_golden():
+    """ResidualMLP (DAC resnet) and Simba against tests/golden/golden_res_dac_resnet.npz / golden_simba_cnf.npz: no oracle run
+    (parameters regenerated from the stored seed and checked against the stored SHA-256)."""
+    from pathlib import Path
+    from test_oracle import GOLDEN_RES, _golden_params
+    for case in GOLDEN_RES:
+        z = np.load(Path(__file__).resolve().parent / "golden" / f"{case.name}.npz")
+        params = _golden_params(z, case)
+        model = H.product_model(case, params)
+        x0, xh, eh = H.product_run(case, model, z["xT"], z["cond"], z["noise"], history=True)
+        msg = f"{case.name}: x0 {H.rel_err(x0, z['x0']):.2e} xt {H.rel_err(xh, z['xt_hist']):.2e} first eval {H.rel_err(eh[0], z['eps_hist'][0]):.2e}"
+        print(msg)
+        assert H.rel_err(eh[0], z["eps_hist"][0]) <= 1e-5, msg
+        assert H.rel_err(x0, z["x0"]) <= 5e-5 and H.rel_err(xh, z["xt_hist"]) <= 5e-5, msg

@@ -295,3 +295,24 @@ def test_net_eval_vjp_refusals():
         t = _t_for(case, np.random.default_rng(1), case.B)
         with pytest.raises(_lib.FlowRLHipUnsupported):
             model(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(cond).cuda(), True, model.params, keep_for_vjp=True)
+
+
+def test_net_eval_vjp_against_committed_golden():
+    """frl_net_eval_train / frl_net_eval_bwd against tests/golden/golden_eval_vjp.npz (every leaf + dL/dx): no oracle run."""
+    import torch
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / "golden_eval_vjp.npz")
+    case = H.Case("golden_eval_vjp", "cddpm", A=6, S=17, T=20, B=40, temb="learnable_fourier", schedule="cosine", act="silu", seed=111)
+    params = orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")})
+    model = H.product_model(case, params)
+    out, ctx = model(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["t"]).cuda(), torch.from_numpy(z["cond"]).cuda(), True, model.params,
+                     keep_for_vjp=True)
+    grads, gx = model.eval_vjp(ctx, torch.from_numpy(z["g"]).cuda(), want_gx=True)
+    torch.cuda.synchronize()
+    assert H.rel_err(out.cpu().numpy(), z["out"]) <= 1e-5
+    got = {"g:" + k: v.cpu().numpy() for k, v in _flatten(grads).items()}
+    assert set(got) == {k for k in z.files if k.startswith("g:")}
+    got["g_x"] = gx.cpu().numpy()
+    for k, v in got.items():
+        r = z[k]
+        assert np.abs(v - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-30), k

@@ -332,7 +332,13 @@ GOLDEN_R2 = [
 ]
 
 
-@pytest.mark.parametrize("case", GOLDEN_R2, ids=lambda c: c.name)
+GOLDEN_RES = [
+    H.Case("golden_res_dac_resnet", "ddpm", A=3, S=11, T=5, B=24, hidden=(256, 256), backbone="residual", ln=True, seed=109),
+    H.Case("golden_simba_cnf", "cnf", A=6, S=17, T=10, B=24, hidden=(256,), backbone="simba", act="relu", seed=110),
+]
+
+
+@pytest.mark.parametrize("case", GOLDEN_R2 + GOLDEN_RES, ids=lambda c: c.name)
 def test_oracle_reproduces_golden_r2(case):
     z = np.load(GOLD / f"{case.name}.npz")
     params = _golden_params(z, case)
@@ -340,6 +346,23 @@ def test_oracle_reproduces_golden_r2(case):
     np.testing.assert_allclose(x0, z["x0"], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(xh, z["xt_hist"], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(eh, z["eps_hist"], rtol=1e-11, atol=1e-13)
+
+
+def test_oracle_reproduces_golden_eval_vjp():
+    """tests/golden/golden_eval_vjp.npz: the float64 backward of ONE per-sample-time evaluation (every leaf + dL/dx)."""
+    import flowrl_oracle_vjp as ov
+    z = np.load(GOLD / "golden_eval_vjp.npz")
+    case = H.Case("golden_eval_vjp", "cddpm", A=6, S=17, T=20, B=40, temb="learnable_fourier", schedule="cosine", act="silu", seed=111)
+    p64 = orc.cast_tree(orc.unflatten_tree({k[2:]: z[k] for k in z.files if k.startswith("p:")}), np.float64)
+    out, cache = ov.backbone_fwd(case.spec, p64, z["x"].astype(np.float64), z["t"].astype(np.float64), z["cond"].astype(np.float64))
+    gref: dict = {}
+    gx = ov.backbone_bwd(case.spec, p64, cache, z["g"].astype(np.float64), gref)
+    np.testing.assert_allclose(out, z["out"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(gx, z["g_x"], rtol=1e-10, atol=1e-12)
+    flat = orc.flatten_tree(gref)
+    assert {"g:" + k for k in flat} == {k for k in z.files if k.startswith("g:")}
+    for k, v in flat.items():
+        np.testing.assert_allclose(v, z["g:" + k], rtol=1e-10, atol=1e-12)
 
 
 def test_oracle_reproduces_golden_critic():
