@@ -471,8 +471,7 @@ static int validate_bwd(const FrlDesc* d) {
   }
   if (pl.H != 256 || pl.TR != 32) { set_error("VJP: only the 256-wide (32x32x2) geometry has a backward kernel"); return FRL_EUNSUPPORTED; }
   if (pl.AR > 12 || pl.CK > 64) { set_error("VJP: x_dim <= 24 and <= 128 condition rows required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
-  if (d->act != FRL_ACT_MISH && d->act != FRL_ACT_SILU && d->act != FRL_ACT_RELU) { set_error("VJP: activation %d has no backward kernel (mish / silu / relu)", d->act); return FRL_EUNSUPPORTED; }
-  return FRL_OK;
+  return FRL_OK;      // every activation of the forward has its derivative in the f32 sweep
 }
 
 // x_dim > 8, more than 24 condition rows or a cond_embedding: the wide sweep build, which exists for the stash path only
@@ -928,7 +927,6 @@ static int eval_bwd_plan(const FrlDesc* desc, EvalBwdPlan& q) {
   if (pl.H != 256 || pl.TR != 32) { set_error("single-evaluation VJP: 256-wide predictors only"); return FRL_EUNSUPPORTED; }
   if (desc->layer_norm) { set_error("single-evaluation VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (desc->backbone != FRL_BACKBONE_MLP) { set_error("single-evaluation VJP: residual backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
-  if (desc->act != FRL_ACT_MISH && desc->act != FRL_ACT_SILU && desc->act != FRL_ACT_RELU) { set_error("single-evaluation VJP: activation %d (mish / silu / relu)", desc->act); return FRL_EUNSUPPORTED; }
   q.Cp = q.e.Dp + q.e.C;
   if (pl.AR > 12 || pl.A + q.Cp > 224) { set_error("single-evaluation VJP: x_dim <= 24 and x_dim + time_dim + cond_dim <= 224 required (got %d, %d)", pl.A, q.Cp); return FRL_EUNSUPPORTED; }
   if (desc->time_embed != FRL_TEMB_NONE && desc->time_dim > 128) { set_error("single-evaluation VJP: time_dim <= 128"); return FRL_EUNSUPPORTED; }

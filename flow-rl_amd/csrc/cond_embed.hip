@@ -163,9 +163,22 @@ __device__ __forceinline__ void cact_grad(int act, float z, float& h, float& d) 
     const float sg = __builtin_amdgcn_rcpf(1.0f + e);
     h = z * sg;
     d = h * (1.0f - sg) + sg;
-  } else {
+  } else if (act == FRL_ACT_RELU) {
     h = fmaxf(z, 0.0f);
     d = z > 0.0f ? 1.0f : 0.0f;
+  } else if (act == FRL_ACT_GELU_TANH) {
+    constexpr float C2 = 2.0f * 0.7978845608028654f, K = 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(-C2 * (z + K * z * z * z), -88.0f, 80.0f) * LOG2E);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + e);
+    h = z * sg;
+    d = sg + h * (1.0f - sg) * C2 * (1.0f + 3.0f * K * z * z);
+  } else if (act == FRL_ACT_TANH) {
+    h = tanhf(z);
+    d = 1.0f - h * h;
+  } else {  // ELU
+    const float e = __builtin_amdgcn_exp2f(fminf(z, 0.0f) * LOG2E);
+    h = z > 0.0f ? z : e - 1.0f;
+    d = z > 0.0f ? 1.0f : e;
   }
 }
 
@@ -243,7 +256,7 @@ int launch_cond_embed_bwd(int act, const float* obs, long long n_states, int par
                           const float* w1, const float* b1, const float* gcf, int gcf_stride, float* scratch, float* g_w0, float* g_b0,
                           float* g_w1, float* g_b1, hipStream_t stream) {
   if (n_states <= 0) return FRL_OK;
-  if (act != FRL_ACT_MISH && act != FRL_ACT_SILU && act != FRL_ACT_RELU) { set_error("cond_embedding backward: activation %d (mish / silu / relu)", act); return FRL_EUNSUPPORTED; }
+  if (act < FRL_ACT_MISH || act > FRL_ACT_ELU) { set_error("cond_embedding backward: activation %d invalid", act); return FRL_EINVAL; }
   const size_t lds = sizeof(float) * ((size_t)in_dim + 2 * COND_EMBED_DIM);
   if (lds > 60000) { set_error("cond_embedding backward: observation width %d too large", in_dim); return FRL_EUNSUPPORTED; }
   if (n_states > 0x7fffffffLL) { set_error("cond_embedding backward: too many states"); return FRL_EUNSUPPORTED; }

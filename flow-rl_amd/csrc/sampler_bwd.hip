@@ -70,9 +70,27 @@ __device__ __forceinline__ void act_grad2(f32x2 z, f32x2& h, f32x2& d) {
     const f32x2 s = {__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
     h = z * s;
     d = h * (1.0f - s) + s;
-  } else {  // RELU
+  } else if constexpr (ACT == FRL_ACT_RELU) {
     h = f32x2{fmaxf(z[0], 0.0f), fmaxf(z[1], 0.0f)};
     d = f32x2{z[0] > 0.0f ? 1.0f : 0.0f, z[1] > 0.0f ? 1.0f : 0.0f};
+  } else if constexpr (ACT == FRL_ACT_GELU_TANH) {
+    // h = z s, s = sigmoid(2u), u = c (z + k z^3) (the forward's form, frl_device.h);  h' = s + h (1 - s) 2 c (1 + 3 k z^2)
+    constexpr float C2 = 2.0f * 0.7978845608028654f, K = 0.044715f;
+    const f32x2 z2 = z * z;
+    const f32x2 m2u = (z2 * (K * -C2) + (-C2)) * z;                                  // -2u
+    f32x2 c = {__builtin_amdgcn_fmed3f(m2u[0], -88.0f, 80.0f), __builtin_amdgcn_fmed3f(m2u[1], -88.0f, 80.0f)};
+    c = c * LOG2E;
+    const f32x2 dd = f32x2{__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])} + 1.0f;
+    const f32x2 s = {__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+    h = z * s;
+    d = (h * (1.0f - s)) * (z2 * (3.0f * K * C2) + C2) + s;
+  } else if constexpr (ACT == FRL_ACT_TANH) {
+    h = f32x2{act_fn<FRL_ACT_TANH>(z[0]), act_fn<FRL_ACT_TANH>(z[1])};
+    d = 1.0f - h * h;
+  } else {  // ELU: h = z (z > 0) | e^z - 1;  h' = 1 | e^z
+    const f32x2 e = {__builtin_amdgcn_exp2f(fminf(z[0], 0.0f) * LOG2E), __builtin_amdgcn_exp2f(fminf(z[1], 0.0f) * LOG2E)};
+    h = f32x2{z[0] > 0.0f ? z[0] : e[0] - 1.0f, z[1] > 0.0f ? z[1] : e[1] - 1.0f};
+    d = f32x2{z[0] > 0.0f ? 1.0f : e[0], z[1] > 0.0f ? 1.0f : e[1]};
   }
 }
 
@@ -908,7 +926,10 @@ int launch_bwd_sweep_phase<FRL_BWD_PHASE>(const FrlDesc& d, const BArgs& b, hipS
     case FRL_ACT_MISH: return launch_sweep<FRL_ACT_MISH>(b, grid, 64 * nw, lds, stream);
     case FRL_ACT_SILU: return launch_sweep<FRL_ACT_SILU>(b, grid, 64 * nw, lds, stream);
     case FRL_ACT_RELU: return launch_sweep<FRL_ACT_RELU>(b, grid, 64 * nw, lds, stream);
-    default: set_error("bwd: activation %d has no VJP kernel (mish / silu / relu)", d.act); return FRL_EUNSUPPORTED;
+    case FRL_ACT_GELU_TANH: return launch_sweep<FRL_ACT_GELU_TANH>(b, grid, 64 * nw, lds, stream);
+    case FRL_ACT_TANH: return launch_sweep<FRL_ACT_TANH>(b, grid, 64 * nw, lds, stream);
+    case FRL_ACT_ELU: return launch_sweep<FRL_ACT_ELU>(b, grid, 64 * nw, lds, stream);
+    default: set_error("bwd: activation %d invalid", d.act); return FRL_EINVAL;
   }
 }
 

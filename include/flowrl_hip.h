@@ -229,7 +229,8 @@ int frl_sampler_fwd_static(const FrlDesc* desc, const FrlParams* params, const F
  * predictor MLP and dL/dxT.  The batch-invariant time branch (O(T * D^2) work) hangs off grad_tb
  * (dL/d(tb), tb[j] = bias_0 + tfeat[j] @ kernel_0[A:A+D']): either the caller differentiates it from grad_tb (a JAX
  * binding gets that from jax.vjp of its own tfeat function) or the library does, see the optional outputs below.
- * This build: DDPM / ContinuousDDPM / CNF update rules (ddpm, ddim, Euler), 256-wide predictor, mish / silu / relu.
+ * This build: DDPM / ContinuousDDPM / CNF update rules (ddpm, ddim, Euler), 256-wide predictor; every activation in f32,
+ * mish / silu / relu in bf16.
  *   FRL_DTYPE_F32: x_dim <= 8 and <= 24 condition rows from xt_hist alone (the backward recomputes each step) or from
  *     the stash of frl_sampler_fwd_train; x_dim <= 24, <= 128 condition rows and a cond_embedding MLP (DACER / QVPO
  *     humanoid: act 17, obs 376 -> 128) through frl_sampler_fwd_train + have_stash only.
@@ -372,7 +373,7 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
  * add_noise (dql.py:88-92, dac.py:113, qvpo.py:140, sdac.py:91, ...): frl_net_eval_train is frl_net_eval that also keeps
  * act(z) / act'(z) of every layer in the workspace; frl_net_eval_bwd then takes dL/d out and writes dL/d of EVERY
  * parameter leaf (predictor, MLP_0, time_embedding, cond_embedding) and optionally dL/dx.  f32, 256-wide predictor,
- * mish / silu / relu, x_dim <= 24, time_dim + cond_dim <= 192 (DACER: 64 + 128), no LayerNorm; deterministic. */
+ * x_dim <= 24, time_dim + cond_dim <= 192 (DACER: 64 + 128), no LayerNorm; deterministic. */
 typedef struct FrlEvalBwdBufs {
   const float* x;     /* (B, A)   as the forward call */
   const float* cond;  /* (n_states, C | cond_in_dim) */

@@ -189,6 +189,8 @@ EVAL_VJP_CASES = [
            cond_embed=True, seed=64),
     H.Case("evjp-wide-cond", "ddpm", A=17, S=128, T=5, B=64, seed=65),
     H.Case("evjp-multi-tile", "ddpm", A=3, S=11, T=5, B=20000, seed=66),
+    H.Case("evjp-gelu-embed", "cddpm", A=6, S=17, T=20, B=50, temb="learnable_fourier", schedule="linear", cond_embed=True, act="gelu_tanh", seed=67),
+    H.Case("evjp-elu", "cnf", A=4, S=9, T=10, B=70, act="elu", clip=False, seed=68),
 ]
 
 

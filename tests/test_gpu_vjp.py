@@ -117,6 +117,10 @@ CASES = [
            clip=False, seed=11),
     H.Case("cnf_raw_t", "cnf", A=8, S=20, T=10, B=64, temb=None, clip=False, seed=12),
     H.Case("cnf_clip_positional", "cnf", A=3, S=11, T=6, B=40, clip=True, act="silu", seed=13),
+    # the other activations of flowrl/functional/activation.py (round 2: every forward activation has its derivative)
+    H.Case("gelu_tanh", "ddpm", A=3, S=11, T=5, B=96, act="gelu_tanh", seed=14),
+    H.Case("tanh_cnf", "cnf", A=6, S=17, T=6, B=64, act="tanh", clip=False, seed=15),
+    H.Case("elu_cddpm", "cddpm", A=3, S=11, T=8, B=64, act="elu", temb="learnable_fourier", schedule="linear", seed=16),
 ]
 
 
@@ -128,6 +132,7 @@ WIDE_CASES = [
     H.Case("dacer_batch_p1", "cddpm", A=17, S=376, T=20, B=70, temb="learnable_fourier", schedule="cosine", cond_embed=True, seed=21),
     H.Case("embed_small_act", "cddpm", A=6, S=17, T=8, B=40, temb="learnable_fourier", schedule="cosine", cond_embed=True, act="silu", seed=22),
     H.Case("wide_cond_no_embed", "ddpm", A=17, S=128, T=5, B=64, seed=23),
+    H.Case("embed_gelu", "cddpm", A=6, S=17, T=6, B=40, temb="learnable_fourier", schedule="linear", cond_embed=True, act="gelu_tanh", seed=24),
     H.Case("wide_x_only", "ddpm", A=12, S=11, T=5, B=50, act="relu", seed=24),
     H.Case("embed_cnf", "cnf", A=8, S=39, T=6, B=2 * 8, particles=8, clip=False, cond_embed=True, seed=25),
 ]
@@ -153,7 +158,7 @@ def test_vjp_matches_oracle(case, stash):
 def test_vjp_unsupported_is_loud():
     import torch
     import flowrl_hip as fh
-    case = H.Case("gelu", "ddpm", A=3, S=11, T=5, B=32, act="gelu_tanh")
+    case = H.Case("fql-512", "ddpm", A=3, S=11, T=5, B=32, hidden=(512, 512), act="gelu_tanh")      # only the 256-wide geometry has a VJP
     params, xT, cond, noise = H.make_inputs(case)
     model = H.product_model(case, params)
     xh = torch.zeros((5, 32, 3), device="cuda")
