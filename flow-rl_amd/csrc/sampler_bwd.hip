@@ -45,6 +45,13 @@ __device__ __forceinline__ void st2(f32x2 v, __amdgpu_buffer_rsrc_t rs, unsigned
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
 }
 
+// LDS-DMA: 64 lanes x 16 B, per-lane global source, LDS destination = wave-uniform base + lane * 16 (+ OFF on both sides)
+template <int OFF>
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
+}
+
 // activation and its derivative for a register pair (shared exp / rcp)
 template <int ACT>
 __device__ __forceinline__ void act_grad2(f32x2 z, f32x2& h, f32x2& d) {
@@ -190,6 +197,21 @@ frl_bwd_sweep_kernel(const BArgs b) {
   for (int idx = tid; idx < a.T * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
   __syncthreads();
 
+  // PHASE 2: act'(z) of the layer being swept arrives through a per-wave 32 KB LDS buffer (two 16 KB halves = 32 pair rows
+  // each), filled by LDS-DMA half a layer ahead.  On this chip every vector load of a wave returns in issue order, so an
+  // HBM-latency act' load sitting between two weight-ring loads stalls the ring (L2 latency, 7 k-steps of lookahead) for the
+  // difference — with one wave per SIMD nothing hides it (round 2: 60 % MFMA busy).  Batched, the latency is paid once per
+  // half layer instead of once per pair row, and the consumer reads LDS.
+  char* s_adw = (char*)(s_coef + a.T * COEF_STRIDE) + wave * 32768;
+  auto issue_half = [&](const float* blk, int half) {          // blk: the 8192-float stash block of one (tile-step, layer)
+    const char* src = (const char*)blk + half * 16384 + lane * 16;
+    char* dst = s_adw + half * 16384;
+    sfor<4>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      sfor<4>([&](auto II) { constexpr int i = decltype(II)::value; dma16<i * 1024>(src + g * 4096, dst + g * 4096); });
+    });
+  };
+
   const unsigned voff_h = ls * (16 * ROWB) + li * 16;
   const unsigned voff_x = ls * (4 * ROWB) + li * 16;
   const unsigned voff_c = ls * ROWB + li * 16;
@@ -237,6 +259,13 @@ frl_bwd_sweep_kernel(const BArgs b) {
 
   acc_t P[NB], Q[NB];
   const long long n_wt = (a.B + TR - 1) / TR;
+  if constexpr (PHASE == 2) {       // first half of the first block this wave sweeps: (its first tile, step T - 1, layer L - 1)
+    const long long wt0 = (long long)blockIdx.x * nw + wave;
+    if (wt0 < n_wt) {
+      issue_half(b.ad + ((size_t)(wt0 * a.T + a.T - 1) * a.L + (a.L - 1)) * 8192, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
 
   for (long long wt = (long long)blockIdx.x * nw + wave; wt < n_wt; wt += (long long)gridDim.x * nw) {
     const long long chain = wt * TR + li;
@@ -513,8 +542,13 @@ frl_bwd_sweep_kernel(const BArgs b) {
         sfor<HRING - 1>([&](auto KI) { hload(rs, KI); });
         zero_init(Q);
         const int drow = l * 32768;
+        const float* blk = b.ad + srow + (size_t)l * 8192;             // this layer's act' block; the next one is layer l - 1
+        auto adload = [&](int rho) -> f32x2 {
+          if constexpr (PHASE == 2) return *(const f32x2*)(s_adw + rho * 512 + lane * 8);
+          else return ld2(rs_ad, voff_d, drow + rho * 512);
+        };
         f32x2 ar[ARD];
-        sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, drow + q * 512); });
+        sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = adload(q); });
         float bop, bn1, bn2 = 0.0f;
         {
           const f32x2 gz = f32x2{P[0][0], P[0][1]} * ar[0];
@@ -523,10 +557,12 @@ frl_bwd_sweep_kernel(const BArgs b) {
         }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
+          if constexpr (PHASE == 2 && k == 0) issue_half(blk, 1);
+          if constexpr (PHASE == 2 && k == NK / 2) issue_half(blk - 8192, 0);
           if constexpr (k + HRING - 1 < NK) hload(rs, std::integral_constant<int, k + HRING - 1>{});
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
             constexpr int rho = (k + 1) / 2;
-            if constexpr (rho + ARD - 1 < NK / 2) ar[(rho + ARD - 1) % ARD] = ld2(rs_ad, voff_d, drow + (rho + ARD - 1) * 512);
+            if constexpr (rho + ARD - 1 < NK / 2) ar[(rho + ARD - 1) % ARD] = adload(rho + ARD - 1);
             const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % ARD];
             st2(gz, rs_gd, voff_d, drow + rho * 512);
             bn1 = gz[0]; bn2 = gz[1];
@@ -552,8 +588,17 @@ frl_bwd_sweep_kernel(const BArgs b) {
         f32x4 rc[WIDE ? 4 : 1][2];       // cond-row operands: one 16-byte load = 4 k-steps, requested 4 k-steps ahead
         const __amdgpu_buffer_rsrc_t rscq = __builtin_amdgcn_make_buffer_rsrc((void*)(WIDE && b.ws_w0cq != nullptr ? b.ws_w0cq : b.ws_w0xq), 0, (WIDE ? 4 : 1) * H * 64 * 4, 0x00020000);   // image m at m * H * 64 floats (the first NK * 64 of each are read)
         if constexpr (WIDE) { if (dcond) sfor<4>([&](auto MI) { constexpr int m = decltype(MI)::value; rc[m][0] = ldw(rscq, voff_l + m * (H * 64 * 4), 0); }); }
+        // layer 0's act' block; after it the sweep moves to (step j - 1, layer L - 1), or to this wave's next tile
+        const float* blk0 = b.ad + srow;
+        const long long wt_n = wt + (long long)gridDim.x * nw;
+        const float* nxt = (jj + 1 < a.T) ? b.ad + (srow - (size_t)a.L * 8192) + (size_t)(a.L - 1) * 8192
+                           : (wt_n < n_wt ? b.ad + ((size_t)(wt_n * a.T + a.T - 1) * a.L + (a.L - 1)) * 8192 : nullptr);
+        auto adload = [&](int rho) -> f32x2 {
+          if constexpr (PHASE == 2) return *(const f32x2*)(s_adw + rho * 512 + lane * 8);
+          else return ld2(rs_ad, voff_d, rho * 512);
+        };
         f32x2 ar[ARD];
-        sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = ld2(rs_ad, voff_d, q * 512); });
+        sfor<ARD>([&](auto QI) { constexpr int q = decltype(QI)::value; ar[q] = adload(q); });
         float bop, bn1, bn2 = 0.0f;
         {
           const f32x2 gz = f32x2{P[0][0], P[0][1]} * ar[0];
@@ -562,11 +607,13 @@ frl_bwd_sweep_kernel(const BArgs b) {
         }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
+          if constexpr (PHASE == 2 && k == 0) issue_half(blk0, 1);
+          if constexpr (PHASE == 2 && k == NK / 2) { if (nxt != nullptr) issue_half(nxt, 0); }
           if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
             rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsxq, voff_l, (k / 4 + RINGL - 1) * 1024);
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
             constexpr int rho = (k + 1) / 2;
-            if constexpr (rho + ARD - 1 < NK / 2) ar[(rho + ARD - 1) % ARD] = ld2(rs_ad, voff_d, (rho + ARD - 1) * 512);
+            if constexpr (rho + ARD - 1 < NK / 2) ar[(rho + ARD - 1) % ARD] = adload(rho + ARD - 1);
             const f32x2 gz = f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]} * ar[rho % ARD];
             st2(gz, rs_gd, voff_d, rho * 512);
             bn1 = gz[0]; bn2 = gz[1];
@@ -918,9 +965,12 @@ int launch_bwd_sweep_phase<FRL_BWD_PHASE>(const FrlDesc& d, const BArgs& b, hipS
   long long per_cu = (n_wt + ncu - 1) / ncu;
   int nw = (int)(per_cu < 1 ? 1 : (per_cu > MAX_WAVES ? MAX_WAVES : per_cu));
   if (nw == 3) nw = 4;
+  const size_t tables = sizeof(float) * ((size_t)a.T * 256 + (size_t)(a.L - 1) * 256 + LAST_PAD + (size_t)a.T * COEF_STRIDE);
+  if (FRL_BWD_PHASE == 2)       // + the per-wave act' staging buffer (32 KB each): fewer waves per workgroup when T is large
+    while (nw > 1 && tables + (size_t)nw * 32768 > 160 * 1024) nw >>= 1;
   const long long nwg = (n_wt + nw - 1) / nw;
   const int grid = (int)(nwg < ncu ? nwg : ncu);
-  const size_t lds = sizeof(float) * ((size_t)a.T * 256 + (size_t)(a.L - 1) * 256 + LAST_PAD + (size_t)a.T * COEF_STRIDE);
+  const size_t lds = tables + (FRL_BWD_PHASE == 2 ? (size_t)nw * 32768 : 0);
   if (lds > 160 * 1024) { set_error("bwd: steps=%d needs %zu B of LDS", a.T, lds); return FRL_EUNSUPPORTED; }
   switch (d.act) {
     case FRL_ACT_MISH: return launch_sweep<FRL_ACT_MISH>(b, grid, 64 * nw, lds, stream);
