@@ -340,8 +340,8 @@ def stub_main(args, world: int, rank: int) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
