@@ -13,6 +13,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
@@ -67,7 +68,10 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> Path:
         cmd = [cc, *FLAGS, *defs, "-c", str(s), "-o", str(o)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
+        t0 = time.perf_counter()
         subprocess.run(cmd, check=True)
+        if verbose:
+            print(f"[build] {o.name}: {time.perf_counter() - t0:.0f} s", flush=True)
 
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
         list(ex.map(compile_one, todo))
