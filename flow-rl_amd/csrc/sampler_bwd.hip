@@ -199,7 +199,7 @@ frl_bwd_sweep_kernel(const BArgs b) {
 
   // PHASE 2: act'(z) of the layer being swept arrives through a per-wave 32 KB LDS buffer (two 16 KB halves = 32 pair rows
   // each), filled by LDS-DMA half a layer ahead.  On this chip every vector load of a wave returns in issue order, so an
-  // HBM-latency act' load sitting between two weight-ring loads stalls the ring (L2 latency, 7 k-steps of lookahead) for the
+  // HBM-latency act' load sitting between two weight-ring loads stalls the ring (L2 latency; 7 k-steps ≈ 1.5 us of lookahead) for the
   // difference — with one wave per SIMD nothing hides it (round 2: 60 % MFMA busy).  Batched, the latency is paid once per
   // half layer instead of once per pair row, and the consumer reads LDS.
   char* s_adw = (char*)(s_coef + a.T * COEF_STRIDE) + wave * 32768;

@@ -440,6 +440,8 @@ int launch_sampler_rs_act(const KArgs& a, hipStream_t stream) {
   if (a.H == 256 && a.AR <= 4 && a.CK <= 12) return launch_inst<32, 256, ACT, 4, 12>(a, stream);
 #endif
 #ifndef FRL_RS_SKIP_B
+  // wide x with the condition rows hoisted per state (DACER / QVPO acting: CK = 0): no 64-register cond operand array
+  if (a.H == 256 && a.AR <= 12 && a.CK == 0) return launch_inst<32, 256, ACT, 12, 1>(a, stream);
   if (a.H == 256 && a.AR <= 12 && a.CK <= 64) return launch_inst<32, 256, ACT, 12, 64>(a, stream);
 #endif
 #ifndef FRL_RS_SKIP_C
