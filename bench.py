@@ -213,12 +213,12 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     return e0.elapsed_time(e1) / iters, flops_alg - kernel_only_ms.hoisted, flops_exec.value
 
 
-TRAFFIC_PROFILE = "profiles/r02_prof_cfg2_default/pmc_summary.json"
+TRAFFIC_PROFILE = "profiles/r02_prof_cfg2_w2/pmc_summary.json"
 
 
 def pmc_traffic_bytes(workload, w):
     """HBM bytes per launch of the sampler kernel from the COMMITTED rocprofv3 PMC passes (scripts/prof_r2.sh ->
-    profiles/r02_prof_cfg2_default/pmc_summary.json; cfg2 at its full batch only): 2 x FETCH_SIZE (gfx950 half-count
+    profiles/r02_prof_cfg2_w2/pmc_summary.json; cfg2 at its full batch only): 2 x FETCH_SIZE (gfx950 half-count
     correction, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KiB.  Not measured in this run (PMC collection needs
     the profiler): the bench line names the file in roofline.traffic_source.  None when no profile matches."""
     f = ROOT / TRAFFIC_PROFILE
@@ -459,6 +459,13 @@ def main():
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         lat = args.tile_policy.startswith("latency") or (args.tile_policy == "auto" and (B + 15) // 16 <= ncu) or (args.tile_policy == "auto" and -(-((B + 31) // 32) // ncu) <= 3 * -(-((B + 31) // 32) // (4 * ncu)))
         kname = "frl_sampler_lat_kernel" if (lat and args.dtype == "f32") else "frl_sampler_rs_kernel"
+        # plan_two_wave (csrc/frl_internal.h): big plain 256-wide f32 batches run the 16-chain geometry at two waves per SIMD
+        c_op = 128 if w["cond_embed"] else w["S"]
+        if (kname == "frl_sampler_rs_kernel" and args.dtype == "f32" and w.get("backbone", "mlp") == "mlp" and not w.get("ln")
+                and all(h == 256 for h in w["hidden"]) and args.rng == "none" and args.tile_policy in ("auto", "throughput")
+                and w["A"] <= 16 and c_op <= 48 and not (w["particles"] >= 4 and c_op >= 32) and B >= 65536 and not vjp
+                and getattr(args, "solver", None) in (None, "ddpm", "ddim")):
+            kname = "frl_sampler_rs_kernel_w2"
         if w.get("backbone", "mlp") != "mlp":
             kname = "frl_sampler_res_kernel"
         if vjp:

@@ -67,6 +67,8 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
     const long long r_lat = (ntiles + cus - 1) / cus, r_thr = (ntiles + 4 * cus - 1) / (4 * cus);
     lat = (sampler_lat16_supports(a) && (a.B + 15) / 16 <= cus) || (r_lat <= 3 * r_thr && sampler_lat_supports(a));
   }
+  if (a.TR == 16 && a.H == 256) lat = false;   // Plan picked the two-wave throughput build (plan_two_wave): the packed images are its
+
   if (lat) {
     switch (act) {
       case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, tile_rows, stream);
@@ -231,7 +233,7 @@ int frl_validate(const FrlDesc* desc) { return validate_desc(desc); }
 size_t frl_workspace_bytes(const FrlDesc* desc) {
   if (validate_desc(desc) != FRL_OK) return 0;
   Plan pl;
-  plan_from_desc(*desc, pl);
+  plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
   return pl.total_floats * sizeof(float);
 }
 
@@ -247,7 +249,7 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     const double cf = desc->cond_embed ? 2.0 * (double)desc->n_states * ((double)desc->cond_in_dim * COND_EMBED_DIM + (double)COND_EMBED_DIM * COND_EMBED_DIM) : 0.0;
     if (executed != nullptr) {
       Plan pl;
-      plan_from_desc(*desc, pl);
+      plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
       *executed = 2.0 * B * T * ((double)pl.XR * H + desc->n_hidden * blk + H * LAST_PAD) + cf + 2.0 * (double)desc->n_states * C * H;
     }
     return 2.0 * B * T * (macs + desc->n_hidden * blk + H * A) + cf;
@@ -257,11 +259,11 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
   macs += (double)desc->hidden[desc->n_hidden - 1] * A;
   if (executed != nullptr) {
     Plan pl;
-    plan_from_desc(*desc, pl);
-    double em = (double)(pl.XR + 2 * pl.CK) * pl.H;             // Dense_0 without the hoisted time slice, padded
+    plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
+    double em = (double)(pl.XR + pl.KS * pl.CK) * pl.H;         // Dense_0 without the hoisted time slice, padded
     for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
     em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
-    if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_cks) - (pl.XR + 2 * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
+    if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_cks) - (pl.XR + pl.KS * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
     *executed = 2.0 * B * T * em + cond_flops + (pl.hoist ? 2.0 * (double)desc->n_states * pl.C * pl.H : 0.0);   // hoisted cond rows: once per state
   }
   return 2.0 * B * T * macs + cond_flops;
@@ -270,19 +272,19 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
 double frl_hoisted_flops(const FrlDesc* desc) {
   if (validate_desc(desc) != FRL_OK) return 0.0;
   Plan pl;
-  plan_from_desc(*desc, pl);
+  plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
   if (!pl.hoist) return 0.0;
   const double evals = (desc->solver == FRL_SOLVER_DPM2 ? 2.0 : 1.0) * desc->steps * (double)pl.B;
   return 2.0 * (evals - (double)desc->n_states) * pl.C * pl.H;
 }
 
 static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
-                                void* workspace, size_t workspace_bytes, void* hip_stream, bool allow_hoist) {
+                                void* workspace, size_t workspace_bytes, void* hip_stream, int plan_flags) {
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr) { set_error("params is NULL"); return FRL_EINVAL; }
   Plan pl;
-  plan_from_desc(*desc, pl, allow_hoist);
+  plan_from_desc(*desc, pl, plan_flags);
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
   for (int l = 0; l <= pl.L; ++l)
@@ -327,7 +329,7 @@ static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, co
 
 int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
                         void* workspace, size_t workspace_bytes, void* hip_stream) {
-  return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, true);
+  return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, PLAN_HOIST | PLAN_W2);
 }
 
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
@@ -336,7 +338,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
   Plan pl;
-  plan_from_desc(*desc, pl);
+  plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
   if (pl.B == 0) {   // empty batch: no chains (the reference returns empty arrays), but the rng still advances
@@ -438,7 +440,7 @@ int frl_sampler_fwd_static(const FrlDesc* desc, const FrlParams* params, const F
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   Plan pl;
-  plan_from_desc(*desc, pl);
+  plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
   const size_t need = pl.total_floats * sizeof(float);
   if (need > (size_t)FRL_STATIC_WS_BYTES) {
     set_error("frl_sampler_fwd_static: this call needs %zu B of scratch, the static buffer holds %zu B (per-state rows of a cond_embedding / "
@@ -458,7 +460,7 @@ static int validate_bwd(const FrlDesc* d) {
   int rc = validate_desc(d);
   if (rc != FRL_OK) return rc;
   Plan pl;
-  plan_from_desc(*d, pl, false);       // the VJP never hoists the condition rows: they are contracted per chain
+  plan_from_desc(*d, pl, 0);           // the VJP never hoists the condition rows: they are contracted per chain
   if (pl.mode > MODE_CNF_EULER) { set_error("VJP: solvers dpm2 / dpm++2m have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->layer_norm) { set_error("VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->backbone != FRL_BACKBONE_MLP) { set_error("VJP: residual backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
@@ -557,7 +559,7 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
   if (rng && bufs->rng_total_chains != 0 && (bufs->rng_chain_offset < 0 || bufs->rng_chain_offset + pl.B > bufs->rng_total_chains)) {
     set_error("bufs.rng_chain_offset / rng_total_chains do not cover this call's chains"); return FRL_EINVAL; }
   if (needs_noise && !rng && bufs->noise == nullptr) { set_error("bufs.noise is NULL but the ddpm solver draws noise every step (or set desc.rng_impl and bufs.rng_key)"); return FRL_EINVAL; }
-  rc = sampler_prepare_impl(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream, false);
+  rc = sampler_prepare_impl(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream, 0);
   if (rc != FRL_OK) return rc;
   if (desc->cond_embed) {
     for (int k = 0; k < 2; ++k)
@@ -623,7 +625,7 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
   float* ws = (float*)workspace;
   // forward tables (coefficients, tb, packed edge layers) — already there after frl_sampler_fwd_train — then the transposed images
   if (!stash) {
-    rc = sampler_prepare_impl(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream, false);
+    rc = sampler_prepare_impl(desc, params, sched, workspace, pl.total_floats * sizeof(float), hip_stream, 0);
     if (rc != FRL_OK) return rc;
   }
   rc = bf16 ? launch_prepare_bwd_bf16(*params, bp16, ws, stream) : launch_prepare_bwd(*params, bp, ws, stream);

@@ -67,22 +67,41 @@ struct Plan {
   size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
 };
 
-inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist = true);
+// Plan flags.  PLAN_HOIST off: the condition rows of Dense_0 stay in the kernel's operand (the chain VJP contracts them
+// per chain).  PLAN_W2 (the forward sampler's entry points only: prepare, run and the sizes they are called with must
+// agree): large plain 256-wide batches may take the 16-chain geometry at two waves per SIMD (plan_two_wave below);
+// every other consumer of a Plan (VJP, single evaluation, critic) has 32-chain kernels only.
+enum { PLAN_HOIST = 1, PLAN_W2 = 2 };
+constexpr long long W2_MIN_CHAINS = 65536;   // 16 chains x 8 waves x 256 CUs x 2 tiles per wave
 
-// allow_hoist = false: the condition rows of Dense_0 stay in the kernel's operand (the chain VJP contracts them per chain)
-inline int plan_from_desc(const FrlDesc& d, Plan& p, bool allow_hoist = true) {
+inline int plan_layout(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST);
+
+// The 16x16x4 geometry at two waves per SIMD (csrc/sampler_rs.hip, frl_sampler_rs_kernel_w2) runs the plain sampler
+// only: f32 MLP backbone, 256 wide, no LayerNorm, no in-kernel draws, ddpm / ddim / Euler updates, condition rows in
+// the operand (x_dim <= 16, cond_dim <= 48), and a batch large enough that every wave still gets two tiles.
+inline bool plan_two_wave(const FrlDesc& d, const Plan& p) {
+  if (d.dtype != FRL_DTYPE_F32 || d.backbone != FRL_BACKBONE_MLP || p.H != 256 || d.layer_norm != 0 || d.rng_impl != FRL_RNG_NONE) return false;
+  if (d.kind != FRL_KIND_CNF && d.solver != FRL_SOLVER_DDPM && d.solver != FRL_SOLVER_DDIM) return false;
+  if (d.tile_policy != FRL_TILE_AUTO && d.tile_policy != FRL_TILE_THROUGHPUT) return false;
+  if (p.A > 16 || p.C > 48 || (d.particles >= 4 && p.C >= 32)) return false;
+  return (long long)d.n_states * d.particles >= W2_MIN_CHAINS;
+}
+
+inline int plan_from_desc(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST) {
   p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps;
   p.L = (d.backbone != FRL_BACKBONE_MLP) ? 1 : d.n_hidden;   // residual classes: Dense_0 -> [blocks] -> Dense_1 around ONE 256-wide trunk
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
   p.AO = p.A; p.x_row0 = 0; p.c_row0 = p.A + p.Dp;
   p.H = d.hidden[0];
-  return plan_layout(d, p, allow_hoist);
+  return plan_layout(d, p, flags);
 }
 
 // Second half of the plan: geometry and workspace layout from the (possibly overridden) dims above.
-inline int plan_layout(const FrlDesc& d, Plan& p, bool allow_hoist) {
+inline int plan_layout(const FrlDesc& d, Plan& p, int flags) {
+  const bool allow_hoist = (flags & PLAN_HOIST) != 0;
   p.TR = (p.H <= 256) ? 32 : 16;
+  if ((flags & PLAN_W2) != 0 && plan_two_wave(d, p)) p.TR = 16;
   p.KS = (p.TR == 32) ? 2 : 4;
   p.NR = (p.TR == 32) ? 16 : 4;
   p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
@@ -249,7 +268,7 @@ inline int bwd_plan_finish(BwdPlan& b, int cond_embed, long long n_states, int d
 }
 
 inline int bwd_plan_from_desc(const FrlDesc& d, BwdPlan& b) {
-  plan_from_desc(d, b.f, false);
+  plan_from_desc(d, b.f, 0);
   return bwd_plan_finish(b, d.cond_embed, d.n_states, b.f.A + b.f.C);
 }
 

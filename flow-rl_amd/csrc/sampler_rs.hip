@@ -38,8 +38,7 @@
 namespace frl {
 
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-frl_sampler_rs_kernel(const KArgs a) {
+__device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
   typedef Geo<TR> G;
   typedef typename G::acc_t acc_t;
   constexpr int KS = G::KS, NR = G::NR, RING = G::RING;
@@ -374,6 +373,23 @@ frl_sampler_rs_kernel(const KArgs a) {
   }
 }
 
+// One wave per SIMD, 512 registers per lane: every geometry.
+template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+frl_sampler_rs_kernel(const KArgs a) {
+  sampler_rs_body<TR, H, ACT, NRX, CKMAX, EXT>(a);
+}
+
+// Two waves per SIMD, 256 registers per lane: the 16-chain geometry of the plain sampler (EXT 0: 249 registers, no
+// spills; the EXT 1 / 2 paths do not fit).  Same body, same results per tile; the second wave fills the issue slots
+// the first leaves between its MFMAs and ring loads (+2 .. 2.6 % at cfg2, same-box A/B in DESIGN.md 5.2).  Picked by
+// plan_two_wave (frl_internal.h) for batches of >= 65536 chains.
+template <int ACT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+frl_sampler_rs_kernel_w2(const KArgs a) {
+  sampler_rs_body<16, 256, ACT, 4, 12, 0>(a);
+}
+
 // ---- launcher --------------------------------------------------------------------------------------
 static int device_cus_rs() {
   static thread_local int cus[16] = {0};
@@ -388,31 +404,49 @@ static int device_cus_rs() {
   return cus[dev];
 }
 
-template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
-static int launch_inst_v(const KArgs& a, hipStream_t stream) {
-  auto kern = frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX, EXT>;
+// `configured`: the launching instantiation's per-device record of the dynamic-LDS size its kernel was last set up for
+static int launch_kern(const void* kern, size_t* configured, int TR, int H, int max_waves, const KArgs& a, hipStream_t stream) {
   const int ncu = device_cus_rs();
   const long long n_wt = (a.B + TR - 1) / TR;
   long long per_cu = (n_wt + ncu - 1) / ncu;
-  int nw = (int)(per_cu < 1 ? 1 : (per_cu > MAX_WAVES ? MAX_WAVES : per_cu));
+  int nw = (int)(per_cu < 1 ? 1 : (per_cu > max_waves ? max_waves : per_cu));
   if (nw == 3) nw = 4;
   long long nwg = (n_wt + nw - 1) / nw;
   const int grid = (int)(nwg < ncu ? nwg : ncu);
   const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE +
                                       (a.ws_ln != nullptr ? (size_t)a.L * 2 * H : 0));
   if (lds > 160 * 1024) { set_error("sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
-  static thread_local size_t configured[16] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && configured[dev] < lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
     configured[dev] = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, stream, a);
-  hipError_t e = hipGetLastError();
+  KArgs args = a;
+  void* argv[] = {(void*)&args};
+  hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(64 * nw), argv, lds, stream);
+  if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_error("sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
+}
+
+template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
+static int launch_inst_v(const KArgs& a, hipStream_t stream) {
+  static thread_local size_t configured[16] = {0};
+  return launch_kern((const void*)frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX, EXT>, configured, TR, H, MAX_WAVES, a, stream);
+}
+
+// the two-wave build: up to eight waves per workgroup (two per SIMD), plain sampler only (plan_two_wave guarantees it)
+template <int ACT>
+static int launch_w2(const KArgs& a, hipStream_t stream) {
+  if constexpr (ACT == FRL_ACT_IDENTITY) { set_error("two-wave build: no identity-activation unit"); return FRL_EINVAL; }
+  else {
+    if (a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr || a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.AR > 4 || a.CK > 12) {
+      set_error("two-wave build asked for a path it does not carry (plan / launch mismatch)"); return FRL_EINVAL; }
+    static thread_local size_t configured[16] = {0};
+    return launch_kern((const void*)frl_sampler_rs_kernel_w2<ACT>, configured, 16, 256, 2 * MAX_WAVES, a, stream);
+  }
 }
 
 // Three builds of every geometry: the plain one (ddpm / ddim / Euler, condition contracted in the kernel) keeps the
@@ -435,7 +469,7 @@ static int launch_inst(const KArgs& a, hipStream_t stream) {
 
 template <int ACT>
 int launch_sampler_rs_act(const KArgs& a, hipStream_t stream) {
-  if (a.H == 256 && a.TR == 16 && a.AR <= 4 && a.CK <= 12) return launch_inst<16, 256, ACT, 4, 12>(a, stream);
+  if (a.H == 256 && a.TR == 16) return launch_w2<ACT>(a, stream);
 #ifndef FRL_RS_SKIP_A
   if (a.H == 256 && a.AR <= 4 && a.CK <= 12) return launch_inst<32, 256, ACT, 4, 12>(a, stream);
 #endif

@@ -202,7 +202,9 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
                         void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Stage 2: (cond_embedding kernel, once per state, when desc.cond_embed) + the persistent fused T-step kernel.  Needs a workspace filled by frl_sampler_prepare
- * for the same desc/params on the same stream (or an earlier, completed one). */
+ * for the same desc/params on the same stream (or an earlier, completed one).  "Same desc" includes n_states and
+ * particles: the kernel geometry (and with it the packed edge-layer images prepare writes) is chosen from the batch
+ * size, e.g. 16-chain tiles at two waves per SIMD from 65536 chains of a plain 256-wide sampler. */
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream);
 

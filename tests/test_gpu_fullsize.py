@@ -140,3 +140,40 @@ def test_cfg5_full_size_vjp(dtype):
     print(f"cfg5-full/{dtype}: additivity {worst_add:.2e}, linearity {worst_lin:.2e}, dL/dxT rows vs their own small run {e_gx:.2e}")
     assert np.all([np.isfinite(v).all() for v in full.values()])
     assert worst_add <= 2e-5 and worst_lin <= (1.5e-2 if dtype == "bf16" else 2e-5) and e_gx <= 3e-5
+
+
+W2_CASES = [
+    H.Case("w2-ddpm-ragged", "ddpm", A=3, S=11, T=5, B=65536 + 37),
+    H.Case("w2-ddim-relu-wide", "ddpm", A=16, S=48, T=4, B=65536 + 16, solver="ddim", act="relu", clip=False, seed=21),
+    H.Case("w2-cnf-nocond", "cnf", A=6, S=0, T=3, B=65536, act="silu", temb=None, clip=False, seed=22, tile="throughput"),
+    H.Case("w2-cddpm-elu", "cddpm", A=8, S=17, T=4, B=65536 + 1, act="elu", temb="learnable_fourier", schedule="cosine", seed=23),
+    H.Case("w2-two-layers-gelu", "ddpm", A=5, S=20, T=3, B=70000, hidden=(256, 256), act="gelu_tanh", seed=24),
+]
+
+
+@pytest.mark.parametrize("case", W2_CASES, ids=lambda c: c.name)
+def test_two_wave_build(case):
+    """Batches of >= 65536 chains of a plain 256-wide sampler run on 16-chain tiles at two waves per SIMD
+    (frl_sampler_rs_kernel_w2, csrc/sampler_rs.hip; plan_two_wave in csrc/frl_internal.h picks it).  A scattered subset of
+    the batch, run on its own (below the threshold: the 32-chain or latency build), must give the same final actions AND
+    the same history rows to rounding, and matches the float64 oracle under the standard f32 bar."""
+    params, xT, cond, noise = H.make_inputs(case)
+    model = H.product_model(case, params)
+    x0, xh, eh = H.product_run(case, model, xT, cond, noise, history=True)
+    assert x0.shape == (case.B, case.A) and np.isfinite(x0).all()
+    rng = np.random.default_rng(11)
+    sel = np.sort(np.concatenate([rng.choice(case.B - 64, 1000, replace=False), np.arange(case.B - 64, case.B)]))   # ragged tail included
+    sub = dataclasses.replace(case, B=len(sel), tile="auto")
+    sn = np.ascontiguousarray(noise[:, sel])
+    sc = None if cond is None else np.ascontiguousarray(cond[sel])
+    y0, yh, zh = H.product_run(sub, H.product_model(sub, params), np.ascontiguousarray(xT[sel]), sc, sn, history=True)
+    ref0, refx, refe = H.oracle_run(sub, params, xT[sel], sc, sn, dtype=np.float64)
+    o32 = H.oracle_run(sub, params, xT[sel], sc, sn, dtype=np.float32)
+    tol = max(1e-5, 4.0 * H.rel_err(o32[0], ref0))
+    e_self = max(H.rel_err(x0[sel], y0), H.rel_err(xh[:, sel], yh), H.rel_err(eh[:, sel], zh))
+    e_or = max(H.rel_err(x0[sel], ref0), H.rel_err(xh[:, sel], refx), H.rel_err(eh[:, sel], refe))
+    e_first = H.rel_err(eh[0][sel], refe[0])
+    print(f"{case.name}: two-wave rows vs their own small run {e_self:.2e}; vs float64 oracle {e_or:.2e} (tol {tol:.1e}); first evaluation {e_first:.2e}")
+    assert e_self <= tol and e_or <= tol and e_first <= 1e-5
+    again, _, _ = H.product_run(case, model, xT, cond, noise, history=False)
+    assert np.array_equal(again, x0), "two-wave build: second run differs (and the history-less build from the history one)"
