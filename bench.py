@@ -213,22 +213,32 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     return e0.elapsed_time(e1) / iters, flops_alg - kernel_only_ms.hoisted, flops_exec.value
 
 
-TRAFFIC_PROFILE = "profiles/r02_prof_cfg2_w2/pmc_summary.json"
+# committed rocprofv3 PMC passes (scripts/prof_r2.sh) per workload at its full batch: (summary file, sampler kernel name)
+TRAFFIC_PROFILES = {
+    "cfg1": ("profiles/r02_prof_cfg1/pmc_summary.json", "frl_sampler_lat_kernel"),
+    "cfg2": ("profiles/r02_prof_cfg2_w2/pmc_summary.json", "frl_sampler_rs_kernel"),
+    "cfg3": ("profiles/r02_prof_cfg3/pmc_summary.json", "frl_sampler_rs_kernel"),
+    "cfg4": ("profiles/r02_prof_cfg4/pmc_summary.json", "frl_sampler_rs_kernel"),
+    "res_dac": ("profiles/r02_prof_res_dac/pmc_summary.json", "frl_sampler_res_kernel"),
+}
 
 
 def pmc_traffic_bytes(workload, w):
-    """HBM bytes per launch of the sampler kernel from the COMMITTED rocprofv3 PMC passes (scripts/prof_r2.sh ->
-    profiles/r02_prof_cfg2_w2/pmc_summary.json; cfg2 at its full batch only): 2 x FETCH_SIZE (gfx950 half-count
-    correction, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in KiB.  Not measured in this run (PMC collection needs
-    the profiler): the bench line names the file in roofline.traffic_source.  None when no profile matches."""
-    f = ROOT / TRAFFIC_PROFILE
-    if workload != "cfg2" or w["B"] != WORKLOADS["cfg2"]["B"] or not f.exists():
-        return None
+    """(HBM bytes per launch of the sampler kernel, source file) from the COMMITTED rocprofv3 PMC passes of this workload
+    at its full batch: 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE, both reported in
+    KiB.  Not measured in this run (PMC collection needs the profiler): the bench line names the file in
+    roofline.traffic_source.  (None, None) when no profile matches."""
+    if workload not in TRAFFIC_PROFILES or w["B"] != WORKLOADS[workload]["B"]:
+        return None, None
+    path, kern = TRAFFIC_PROFILES[workload]
+    f = ROOT / path
+    if not f.exists():
+        return None, None
     pm = json.loads(f.read_text())
-    k = [v for name, v in pm.items() if "frl_sampler_rs_kernel" in name]
+    k = [v for name, v in pm.items() if kern in name]
     if not k or "FETCH_SIZE" not in k[0] or "WRITE_SIZE" not in k[0]:
-        return None
-    return (2.0 * k[0]["FETCH_SIZE"]["mean"] + k[0]["WRITE_SIZE"]["mean"]) * 1024.0
+        return None, None
+    return (2.0 * k[0]["FETCH_SIZE"]["mean"] + k[0]["WRITE_SIZE"]["mean"]) * 1024.0, path
 
 
 def cpu_baseline(w, budget_s=15.0):
@@ -483,6 +493,7 @@ def main():
             flops_alg, k_ms = 3.0 * flops_alg, f_ms + b_ms
             vjp_parts = {"forward_ms": f_ms, "backward_ms": b_ms}
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
+        traffic, traffic_src = (None, None) if (vjp or args.act or args.layers or args.dtype != "f32" or args.rng != "none" or args.tile_policy != "auto") else pmc_traffic_bytes(args.workload, w)
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         if args.dtype == "bf16" and not vjp:
             kname = "frl_sampler_bf16_kernel"
@@ -495,8 +506,8 @@ def main():
                        "chains_per_s": value / T, "prepare": "cached across calls" if args.cache_prepare else "every call", "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "traffic": None if (vjp or args.act or args.layers or args.dtype != "f32") else pmc_traffic_bytes(args.workload, w), "traffic_unit": "bytes/launch",
-                         "traffic_source": f"committed rocprofv3 PMC passes ({TRAFFIC_PROFILE}), not measured in this run",
+                         "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": f"committed rocprofv3 PMC passes ({traffic_src}), not measured in this run" if traffic_src else None,
                          "algorithmic_hbm_bytes": B * (4 * (2 * A + (T * A if (w["kind"] != "cnf" and args.rng == "none") else 0)) + 4 * S // w["particles"]),
                          "kernel": kname, "kernel_ms": k_ms,
                          "flops_algorithmic": flops_alg, "flops_hoisted_not_credited": getattr(kernel_only_ms, "hoisted", 0.0) * (3.0 if vjp else 1.0),
