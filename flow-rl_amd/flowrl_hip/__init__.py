@@ -14,6 +14,7 @@ __version__ = "0.1.0"
 from . import _lib  # noqa: F401
 from . import random  # noqa: F401
 from . import autograd  # noqa: F401  (torch.autograd bridge: jax.grad's place around sample / apply)
+from . import model  # noqa: F401  (Model.apply_gradient: TrainState, adam, clip_by_global_norm)
 from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, ResidualMLP, Simba, PositionalEmbedding,  # noqa: F401
                      LearnableFourierEmbedding, init_params, tree_from_numpy, tree_to)
 from ._lib import FlowRLHipError, FlowRLHipUnsupported  # noqa: F401
