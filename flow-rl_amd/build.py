@@ -32,7 +32,7 @@ SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []),
           [("sampler_rs.hip", f"sampler_rs_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(7)] + \
           [("sampler_res.hip", f"sampler_res_act{a}", [f"-DFRL_RES_ACT={a}"]) for a in range(6)] + \
           [("sampler_lat.hip", f"sampler_lat_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(7)]   # 6 = identity: the post-activation-LayerNorm units
-HEADERS = [CSRC / "frl_internal.h", CSRC / "frl_device.h", CSRC / "frl_bf16.h", CSRC / "frl_rng.h", ROOT / "include" / "flowrl_hip.h"]
+HEADERS = [CSRC / "frl_internal.h", CSRC / "frl_device.h", CSRC / "frl_bf16.h", CSRC / "frl_rng.h", CSRC / "frl_actgrad.h", ROOT / "include" / "flowrl_hip.h"]
 FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++17", "-Wno-unused-value",
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 

@@ -491,6 +491,28 @@ size_t frl_bwd_workspace_bytes(const FrlDesc* desc) {
   return bp.total_floats * sizeof(float);
 }
 
+// The training forward of a SMALL batch (an actor update on a few hundred transitions) runs as the latency build with the
+// stash kept (csrc/sampler_lat.hip, STASH): four waves per 32-chain tile instead of one, a quarter of the serial MFMA chain
+// per step (B = 256, T = 5: 0.415 ms -> see DESIGN.md 5.4).  Same rule of thumb as the forward's tile policy, one notch more
+// conservative because of the scattered stash stores: latency rounds (one tile per CU) at most twice the throughput rounds.
+static bool lat_train_ok(const KArgs& a) {
+  if (a.H != 256 || a.TR != 32 || a.ws_ln != nullptr || a.NE != a.T || !sampler_lat_supports(a)) return false;
+  const long long n_wt = (a.B + 31) / 32, cus = device_cus();
+  return (n_wt + cus - 1) / cus <= 2 * ((n_wt + 4 * cus - 1) / (4 * cus));
+}
+static int launch_lat_train(const BArgs& b, int act, const float* wl_raw, hipStream_t stream) {
+  KArgs a = b.k;
+  a.stash_h = b.hd; a.stash_a = b.ad; a.wl_raw = wl_raw; a.ln_post_act = 0;
+  switch (act) {
+    case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, 32, stream);
+    case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, 32, stream);
+    case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, 32, stream);
+    case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, 32, stream);
+    case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, 32, stream);
+    default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, 32, stream);
+  }
+}
+
 // Kernel arguments shared by the training forward and the backward: forward tables + stash / image pointers of the workspace.
 static void fill_bwd_args(const FrlDesc* desc, const FrlParams* params, const Plan& pl, const BwdPlan& bp, const BwdPlan16& bp16,
                           bool bf16, float* ws, const float* cond, BArgs& b) {
@@ -584,6 +606,7 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
       a.rng_total = bufs->rng_total_chains > 0 ? bufs->rng_total_chains : pl.B;
     }
   }
+  if (!bf16 && lat_train_ok(a)) return launch_lat_train(b, desc->act, params->kernel[pl.L], stream);
   return bf16 ? launch_sampler_bwd_bf16(*desc, b, 1, stream) : launch_sampler_bwd(*desc, b, 1, stream);
 }
 
@@ -1026,6 +1049,7 @@ int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEv
   BArgs b;
   fill_eval_bargs(desc, params, q, ws, b);
   b.k.xT = bufs->x; b.k.x0 = bufs->out;
+  if (lat_train_ok(b.k)) return launch_lat_train(b, q.e.d.act, params->kernel[pl.L], stream);
   return launch_sampler_bwd(q.e.d, b, 1, stream);
 }
 

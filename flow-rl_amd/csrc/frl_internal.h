@@ -169,6 +169,8 @@ struct KArgs {
   int XR, AR, CK, merged, n_l0, NS, ntiles;
   const void* ws_bf16;                    // bf16 weight stream image (bf16 variant only)
   int bf_nxk, bf_cks, bf_l0c, bf_ns;
+  float* stash_h; float* stash_a;         // latency build as the TRAINING forward (small batches): h_l = act(z_l) and act'(z_l) of
+                                          // every layer and step in the chain VJP's stash layout (BArgs.hd / ad), else NULL
 };
 
 // Residual-backbone part of the sampler's arguments (csrc/sampler_res.hip): block i = Dense (H, 4H) -> act -> Dense (4H, H)

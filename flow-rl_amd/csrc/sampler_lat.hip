@@ -19,10 +19,9 @@
 // has CUs (FrlDesc.tile_policy overrides).
 #include "frl_device.h"
 #include "frl_rng.h"
+#include "frl_actgrad.h"
 
 namespace frl {
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int NBW> struct WVec;
 template <> struct WVec<2> {
@@ -38,9 +37,17 @@ template <> struct WVec<4> {
   }
 };
 
-template <int TR, int H, int ACT, int NRX, int CKMAX>
+// STASH: the kernel is the TRAINING forward of a small batch (frl_sampler_fwd_train / frl_net_eval_train below the
+// throughput regime): it also writes h_l = act(z_l) and act'(z_l) of every layer and step where the chain VJP's backward
+// sweep and dW kernel read them (sampler_bwd.hip: block (tile-step, layer) of 64 pair rows x 64 lanes x 2 floats, k-step
+// k = 16 block + r of the one-wave-per-tile layout on pair row k / 2, element k & 1).  This wave's register (jb, r) of lane
+// (li, ls) is feature 64 w + 2 (ROWR(r) + 4 ls) + jb, which that layout keeps at
+//     k = 64 (w >> 1) + 32 (r & 1) + 16 jb + ((r >> 1) & 1) + 2 ls + 8 (w & 1) + 4 (r >> 3),   lane li + 32 ((r >> 2) & 1)
+// so registers r and r | 2 are the two floats of ONE 8-byte stash element: a per-lane base plus compile-time offsets.
+template <int TR, int H, int ACT, int NRX, int CKMAX, bool STASH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_lat_kernel(const KArgs a) {
+  static_assert(!STASH || (TR == 32 && H == 256), "the stash layout is the 32-chain, 256-wide one");
   typedef Geo<TR> G;                // 32: MFMA 32x32x2, 16: MFMA 16x16x4 (tiles of 16 chains: half the latency again)
   typedef typename G::acc_t acc_t;
   constexpr int NR = G::NR, KS = G::KS;
@@ -89,6 +96,8 @@ frl_sampler_lat_kernel(const KArgs a) {
   const unsigned voff_h = ls * ROWB + voff_col;         // hidden / cond rows: k-step's row 2 ks + ls
   const unsigned voff_x = ls * (4 * ROWB) + voff_col;   // Dense_0 x rows: ROWR(n) + 4 ls
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_w0p, 0, a.w0p_bytes, 0x00020000);
+  const unsigned voff_st = (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + ls) * 512 + li * 8;   // STASH: this lane's part of the element address
+  auto stash_off = [](int jb, int rp) { return (16 * (rp & 1) + 8 * jb + 2 * (rp >> 3)) * 512 + 256 * ((rp >> 2) & 1); };   // rp: bit 1 clear
 
   // Dense_L operands stay resident: k-step (jb, r) contracts feature FW w + NBW (ROWR(r) + 4 ls) + jb, lane i = output row
   float wl[NBW][NR];
@@ -143,6 +152,9 @@ frl_sampler_lat_kernel(const KArgs a) {
 
     for (int j = 0; j < a.NE; ++j) {
       acc_t acc[NBW];
+      const size_t srow = STASH ? ((size_t)tile * a.NE + j) * a.L * 8192 : 0;      // floats: this tile-step's L stash blocks
+      const __amdgpu_buffer_rsrc_t rs_hd = __builtin_amdgcn_make_buffer_rsrc((void*)(STASH ? a.stash_h + srow : nullptr), 0, STASH ? a.L * 32768 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(STASH ? a.stash_a + srow : nullptr), 0, STASH ? a.L * 32768 : 0, 0x00020000);
       // ---------------- Dense_0 ------------------------------------------------------------------------
       if (a.lat_tb_global) {
         const float* trow = a.ws_tb + (size_t)j * H + FW * wave;
@@ -244,7 +256,18 @@ frl_sampler_lat_kernel(const KArgs a) {
               constexpr int q = decltype(QI)::value;
               const int ks = (FW / KS) * wave + G::rowr(4 * q) + 4 * ls;
               f32x4 v;
-              sfor<4>([&](auto EI) { constexpr int e = decltype(EI)::value; v[e] = act_fn<ACT>(acc[jb][4 * q + e]); });
+              if constexpr (STASH) {
+                sfor<2>([&](auto EI) {
+                  constexpr int e = decltype(EI)::value;
+                  f32x2 h, d;
+                  act_grad2<ACT>(f32x2{acc[jb][4 * q + e], acc[jb][4 * q + e + 2]}, h, d);
+                  v[e] = h[0]; v[e + 2] = h[1];
+                  st2(h, rs_hd, voff_st, (l - 1) * 32768 + stash_off(jb, 4 * q + e));
+                  st2(d, rs_ad, voff_st, (l - 1) * 32768 + stash_off(jb, 4 * q + e));
+                });
+              } else {
+                sfor<4>([&](auto EI) { constexpr int e = decltype(EI)::value; v[e] = act_fn<ACT>(acc[jb][4 * q + e]); });
+              }
               *(f32x4*)(abuf + (((ks >> 2) * 64) + jb * TR + li) * 4) = v;
             });
           });
@@ -284,6 +307,21 @@ frl_sampler_lat_kernel(const KArgs a) {
       // ---------------- Dense_L, split-K over the waves ------------------------------------------------------
       acc_t O;
       sfor<NR>([&](auto RI) { O[decltype(RI)::value] = 0.0f; });
+      if constexpr (STASH) {
+        sfor<NBW>([&](auto JI) {
+          constexpr int jb = decltype(JI)::value;
+          sfor<NR / 2>([&](auto MI) {
+            constexpr int m = decltype(MI)::value;
+            constexpr int rp = 4 * (m >> 1) + (m & 1);      // registers rp and rp | 2 share a stash element
+            f32x2 h, d;
+            act_grad2<ACT>(f32x2{acc[jb][rp], acc[jb][rp + 2]}, h, d);
+            st2(h, rs_hd, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
+            st2(d, rs_ad, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
+            O = G::mfma(wl[jb][rp], h[0], O);
+            O = G::mfma(wl[jb][rp + 2], h[1], O);
+          });
+        });
+      } else {
       sfor<NBW>([&](auto JI) {
         constexpr int jb = decltype(JI)::value;
         sfor<NR>([&](auto RI) {
@@ -291,6 +329,7 @@ frl_sampler_lat_kernel(const KArgs a) {
           O = G::mfma(wl[jb][r], act_fn<ACT>(acc[jb][r]), O);
         });
       });
+      }
       {
         float* part = s_act + (phase++ & 1) * (H * TR);
         sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; part[(wave * NR + r) * 64 + lane] = O[r]; });
@@ -375,9 +414,9 @@ frl_sampler_lat_kernel(const KArgs a) {
   }
 }
 
-template <int TR, int H, int ACT, int NRX, int CKMAX>
+template <int TR, int H, int ACT, int NRX, int CKMAX, bool STASH = false>
 static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
-  auto kern = frl_sampler_lat_kernel<TR, H, ACT, NRX, CKMAX>;
+  auto kern = frl_sampler_lat_kernel<TR, H, ACT, NRX, CKMAX, STASH>;
   a.AR = 4 * ((a.A + 4 * Geo<TR>::KS - 1) / (4 * Geo<TR>::KS));   // x k-steps: four of them contract 4 KS rows (ROWR(n) + 4 s)
   a.CK = (a.C + Geo<TR>::KS - 1) / Geo<TR>::KS;
   const long long ntiles = (a.B + TR - 1) / TR;
@@ -402,6 +441,14 @@ int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
   const bool can16 = sampler_lat16_supports(a), can32 = sampler_lat_supports(a);
   bool use16 = can16 && (a.B + 15) / 16 <= ncu;
   if (tile_rows == 16) use16 = true; else if (tile_rows == 32) use16 = false;
+  if (a.stash_h != nullptr) {      // the training forward of a small batch: 32-chain tiles, 256 wide, stash kept (capi.hip: lat_train_ok)
+    if constexpr (ACT == FRL_ACT_IDENTITY) { set_error("latency training forward: no identity-activation unit"); return FRL_EINVAL; }
+    else {
+      if (a.H != 256 || !can32 || a.stash_a == nullptr || a.ws_ln != nullptr || a.NE != a.T) { set_error("latency training forward: unsupported configuration (H %d, evaluations %d / steps %d)", a.H, a.NE, a.T); return FRL_EUNSUPPORTED; }
+      const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;
+      return narrow ? launch_lat_inst<32, 256, ACT, 4, 12, true>(a, ncu, stream) : launch_lat_inst<32, 256, ACT, 12, 64, true>(a, ncu, stream);
+    }
+  }
   if (use16 ? !can16 : !can32) { set_error("latency sampler: no %d-chain-tile build for this configuration (H %d, x_dim %d, operand cond rows %d)", use16 ? 16 : 32, a.H, a.A, a.C); return FRL_EUNSUPPORTED; }
   if (use16) {
     const bool narrow = (a.C + 3) / 4 <= 12;
