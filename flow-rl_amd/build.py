@@ -28,7 +28,7 @@ SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []),
            ("cond_embed.hip", "cond_embed", []), ("critic_select.hip", "critic_select", []), ("time_bwd.hip", "time_bwd", []), ("rng.hip", "rng", []), ("net_eval.hip", "net_eval", []),
            ("sampler_bf16.hip", "sampler_bf16", ["-fno-slp-vectorize"]),
            ] + [("sampler_bwd_bf16.hip", f"sampler_bwd_bf16_p{p}", ["-fno-slp-vectorize", f"-DFRL_BWD16_PHASE={p}"]) for p in range(3)] + \
-          [("sampler_bwd.hip", f"sampler_bwd_p{p}", [f"-DFRL_BWD_PHASE={p}"]) for p in range(3)] + \
+          [("sampler_bwd.hip", f"sampler_bwd_p{p}", [f"-DFRL_BWD_PHASE={p}"]) for p in range(3)] + [("sampler_bwd_lat.hip", "sampler_bwd_lat", [])] + \
           [("sampler_rs.hip", f"sampler_rs_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(7)] + \
           [("sampler_res.hip", f"sampler_res_act{a}", [f"-DFRL_RES_ACT={a}"]) for a in range(6)] + \
           [("sampler_lat.hip", f"sampler_lat_act{a}", [f"-DFRL_RS_ACT={a}"]) for a in range(7)]   # 6 = identity: the post-activation-LayerNorm units

@@ -365,6 +365,9 @@ int launch_random_fill(const uint32_t* key, int impl, long long n, void* out, in
 
 int launch_prepare_bwd(const FrlParams& p, const BwdPlan& bp, float* ws, hipStream_t stream);
 int launch_sampler_bwd(const FrlDesc& d, const BArgs& a, int phase, hipStream_t stream);   // phase 0 recompute + backward, 1 training forward, 2 backward from the stash
+// latency build of the backward sweep from the stash (csrc/sampler_bwd_lat.hip): four waves per 32-chain tile, small batches
+bool bwd_sweep_lat_supports(const BArgs& b);
+int launch_bwd_sweep_lat(const BArgs& b, hipStream_t stream);
 template <int PHASE> int launch_bwd_sweep_phase(const FrlDesc& d, const BArgs& b, hipStream_t stream);   // one translation unit each
 template <> int launch_bwd_sweep_phase<0>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
 template <> int launch_bwd_sweep_phase<1>(const FrlDesc& d, const BArgs& b, hipStream_t stream);

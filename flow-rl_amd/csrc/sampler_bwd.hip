@@ -933,7 +933,8 @@ int launch_bwd_sweep_phase<FRL_BWD_PHASE>(const FrlDesc& d, const BArgs& b, hipS
 // phase 1: the training forward alone; phase 0 / 2: the sweep (with / without recompute), the dW kernel and the reduce
 int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, int phase, hipStream_t stream) {
   if (phase == 1) return launch_bwd_sweep_phase<1>(d, b, stream);
-  int rc = (phase == 2) ? launch_bwd_sweep_phase<2>(d, b, stream) : launch_bwd_sweep_phase<0>(d, b, stream);
+  int rc = (phase == 2) ? (bwd_sweep_lat_supports(b) ? launch_bwd_sweep_lat(b, stream) : launch_bwd_sweep_phase<2>(d, b, stream))
+                        : launch_bwd_sweep_phase<0>(d, b, stream);
   if (rc != FRL_OK) return rc;
   const long long g2 = b.n_part;                        // one partial slot per workgroup (BwdPlan.n_part)
   const size_t lds2 = sizeof(float) * 4 * 256 * 33;     // two (X, G) tile pairs
