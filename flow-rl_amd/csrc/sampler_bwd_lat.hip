@@ -19,7 +19,7 @@
 //
 // No activation is evaluated here (act' was stashed), so there is ONE kernel per operand width, not one per activation.
 // Results equal the one-wave sweep's up to the order of the split-K sums; the dW kernel and the fixed-order reduce are
-// shared.  Not built: the cond_embedding's dL/dcfeat accumulation (those calls stay on the one-wave sweep).
+// shared.
 #include "frl_device.h"
 #include "frl_actgrad.h"
 
@@ -31,7 +31,11 @@ __device__ __forceinline__ f32x2 ld2b(__amdgpu_buffer_rsrc_t rs, unsigned voff, 
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
 
-template <int NRX>
+// DCOND (a cond_embedding, dacer.py:141-162): dL/dcfeat[chain] = sum over steps of W0[cond rows] dL/dz_0, four 32-row blocks
+// that stay in accumulators over the whole step loop (split-K partials, summed over the waves once per tile); the A
+// operands come from the packed image BArgs.ws_w0cq (frl_bwd_prepare_kernel: [4 blocks][k-step / 4][lane][4] in the one-wave
+// k-step order), where this wave's k-steps (jb, r) and (jb, r | 2) are two adjacent floats — the index map of the stash.
+template <int NRX, bool DCOND>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_bwd_sweep_lat_kernel(const BArgs b) {
   typedef Geo<32> G;
@@ -63,6 +67,9 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
   const unsigned voff_st = (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + ls) * 512 + li * 8;   // stash element address, per-lane part
   auto stash_off = [](int jb, int rp) { return (16 * (rp & 1) + 8 * jb + 2 * (rp >> 3)) * 512 + 256 * ((rp >> 2) & 1); };   // rp: bit 1 clear
   const __amdgpu_buffer_rsrc_t rs_wlt = __builtin_amdgcn_make_buffer_rsrc((void*)b.ws_wlt, 0, a.XR * ROWB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cq = __builtin_amdgcn_make_buffer_rsrc((void*)(DCOND ? b.ws_w0cq : b.ws_wlt), 0, DCOND ? 4 * H * 64 * 4 : 0, 0x00020000);
+  const unsigned voff_cq = (unsigned)((16 * (wave >> 1) + 2 * (wave & 1)) * 256 + li * 4 + 2 * ls) * 4;
+  auto cq_off = [](int m, int jb, int rp) { return (m * (H * 64) + (8 * (rp & 1) + 4 * jb + (rp >> 3)) * 256 + 128 * ((rp >> 2) & 1)) * 4; };   // bytes; rp: bit 1 clear
 
   // Dense_0's x rows stay resident: k-step (jb, r) contracts feature FW w + NBW (ROWR(r) + 4 ls) + jb, lane i = action row
   float w0x[NBW][NR];
@@ -89,6 +96,8 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
     const long long chain = (long long)tile * TR + li;
     const bool valid = chain < a.B;
 
+    acc_t OC[DCOND ? 4 : 1];
+    if constexpr (DCOND) sfor<4>([&](auto MI) { sfor<NR>([&](auto RI) { OC[decltype(MI)::value][decltype(RI)::value] = 0.0f; }); });
     float gx[NRX];      // dL/dx_{j+1}, same register layout as the chain state
     sfor<NRX>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
@@ -220,16 +229,27 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
       // ================= dL/dz_0 -> stash; dL/dx_j (net part) = W0[x rows] dL/dz_0, split-K over the waves ==========
       acc_t OX;
       sfor<NR>([&](auto RI) { OX[decltype(RI)::value] = 0.0f; });
-      sfor<NBW>([&](auto JI) {
-        constexpr int jb = decltype(JI)::value;
-        sfor<NR / 2>([&](auto MI) {
-          constexpr int m = decltype(MI)::value;
-          constexpr int rp = 4 * (m >> 1) + (m & 1);
-          const f32x2 gz = f32x2{acc[jb][rp], acc[jb][rp + 2]} * adv[jb][m];
-          st2(gz, rs_gd, voff_st, stash_off(jb, rp));
-          OX = G::mfma(w0x[jb][rp], gz[0], OX);
-          OX = G::mfma(w0x[jb][rp + 2], gz[1], OX);
-        });
+      constexpr int NPAIR = NBW * NR / 2;      // register pairs = stash elements per lane: pair p = (jb, m)
+      f32x2 cq[DCOND ? 2 : 1][DCOND ? 4 : 1];     // cond-row operands of pairs p and p + 1 (one pair ahead)
+      auto cq_load = [&](auto PI) {
+        constexpr int p = decltype(PI)::value, jb = p / (NR / 2), m = p % (NR / 2), rp = 4 * (m >> 1) + (m & 1);
+        sfor<4>([&](auto CI) { constexpr int c = decltype(CI)::value; cq[p & 1][c] = ld2b(rs_cq, voff_cq, cq_off(c, jb, rp)); });
+      };
+      if constexpr (DCOND) cq_load(std::integral_constant<int, 0>{});
+      sfor<NPAIR>([&](auto PI) {
+        constexpr int p = decltype(PI)::value, jb = p / (NR / 2), m = p % (NR / 2), rp = 4 * (m >> 1) + (m & 1);
+        if constexpr (DCOND && p + 1 < NPAIR) cq_load(std::integral_constant<int, p + 1>{});
+        const f32x2 gz = f32x2{acc[jb][rp], acc[jb][rp + 2]} * adv[jb][m];
+        st2(gz, rs_gd, voff_st, stash_off(jb, rp));
+        OX = G::mfma(w0x[jb][rp], gz[0], OX);
+        OX = G::mfma(w0x[jb][rp + 2], gz[1], OX);
+        if constexpr (DCOND) {
+          sfor<4>([&](auto CI) {
+            constexpr int c = decltype(CI)::value;
+            OC[c] = G::mfma(cq[p & 1][c][0], gz[0], OC[c]);
+            OC[c] = G::mfma(cq[p & 1][c][1], gz[1], OC[c]);
+          });
+        }
       });
       {
         float* part = s_act + (phase++ & 1) * (H * TR);
@@ -244,6 +264,23 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
         });
       }
     }
+    if constexpr (DCOND) {
+      // the four waves' partial dL/dcfeat tiles meet in LDS, one 32-row block per phase; wave m writes block m
+      sfor<4>([&](auto MI) {
+        constexpr int m = decltype(MI)::value;
+        float* part = s_act + (phase++ & 1) * (H * TR);
+        sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; part[(wave * NR + r) * 64 + lane] = OC[m][r]; });
+        __syncthreads();
+        if (wave == m && valid) {
+          sfor<NR>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            float sum = 0.0f;
+            sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; sum += part[(w * NR + r) * 64 + lane]; });
+            b.gcf[chain * COND_EMBED_DIM + 32 * m + G::rowr(r) + 4 * ls] = sum;
+          });
+        }
+      });
+    }
     if (b.g_xT != nullptr && wave == 0) {
       sfor<NRX>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
@@ -254,9 +291,9 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
   }
 }
 
-template <int NRX>
+template <int NRX, bool DCOND>
 int launch_inst(const BArgs& b, hipStream_t stream) {
-  auto kern = frl_bwd_sweep_lat_kernel<NRX>;
+  auto kern = frl_bwd_sweep_lat_kernel<NRX, DCOND>;
   const KArgs& a = b.k;
   const long long ntiles = (a.B + 31) / 32;
   const int ncu = device_cus();
@@ -274,10 +311,10 @@ int launch_inst(const BArgs& b, hipStream_t stream) {
 }  // namespace
 
 // The rule of capi.hip's lat_train_ok for the forward half: small batches (latency rounds at most twice the throughput
-// rounds), 256 wide, 32-chain tiles, a stash to read, and no dL/dcfeat to accumulate.
+// rounds), 256 wide, 32-chain tiles, and a stash to read.
 bool bwd_sweep_lat_supports(const BArgs& b) {
   const KArgs& a = b.k;
-  if (a.H != 256 || a.TR != 32 || a.L < 1 || a.NE != a.T || b.gcf != nullptr || (b.eps_hist == nullptr && a.mode != MODE_EVAL)) return false;
+  if (a.H != 256 || a.TR != 32 || a.L < 1 || a.NE != a.T || (b.gcf != nullptr && b.ws_w0cq == nullptr) || (b.eps_hist == nullptr && a.mode != MODE_EVAL)) return false;
   if (a.AR > 12 || a.A > 24 || b.ws_wlt == nullptr || a.AR > (b.ge_stride >> 6)) return false;
   const long long n_wt = (a.B + 31) / 32, cus = device_cus();
   return (n_wt + cus - 1) / cus <= 2 * ((n_wt + 4 * cus - 1) / (4 * cus));
@@ -285,7 +322,11 @@ bool bwd_sweep_lat_supports(const BArgs& b) {
 
 int launch_bwd_sweep_lat(const BArgs& b, hipStream_t stream) {
   // the dL/deps stash holds ge_stride / 64 registers per lane (4 | 12: BwdPlan.wide), all of which the dW kernel reads
-  return (b.ge_stride >> 6) <= 4 ? launch_inst<4>(b, stream) : launch_inst<12>(b, stream);
+  if (b.gcf != nullptr) {      // a cond_embedding always takes the wide operand build (128 condition rows)
+    if ((b.ge_stride >> 6) <= 4) { set_error("latency backward sweep: dL/dcfeat with the narrow dL/deps stash"); return FRL_EINVAL; }
+    return launch_inst<12, true>(b, stream);
+  }
+  return (b.ge_stride >> 6) <= 4 ? launch_inst<4, false>(b, stream) : launch_inst<12, false>(b, stream);
 }
 
 }  // namespace frl

@@ -1,0 +1,39 @@
+"""Wall time of one training-size chain VJP (training forward + backward from the stash), HIP events over 50 calls.
+usage: python scripts/dev/time_train_step.py [dql|dacer] [batch]"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path[:0] = [str(ROOT / "tests"), str(ROOT / "oracle"), str(ROOT / "flow-rl_amd")]
+import helpers as H  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "dql"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+if which == "dacer":
+    case = H.Case("dacer", "cddpm", A=17, S=376, T=20, B=B, temb="learnable_fourier", schedule="cosine", cond_embed=True, seed=1)
+else:
+    case = H.Case("dql", "ddpm", A=3, S=11, T=5, B=B, seed=1)
+params, xT, cond, noise = H.make_inputs(case)
+model = H.product_model(case, params)
+x, c, nz = torch.from_numpy(xT).cuda(), torch.from_numpy(cond).cuda(), torch.from_numpy(noise).cuda()
+g = torch.randn(case.B, case.A, device="cuda")
+
+
+def step():
+    _, x0, hist = model.sample(None, x, c, True, case.solver, noise=nz, params=model.params, keep_for_vjp=True)
+    return model.sample_vjp(hist[0], g, c, case.solver, params=model.params, ctx=hist[2])
+
+
+for _ in range(10):
+    step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50):
+    step()
+e1.record()
+torch.cuda.synchronize()
+print(f"{which} B={B} T={case.T}: {e0.elapsed_time(e1) / 50:.3f} ms per forward+backward (host launch overhead included)")
