@@ -215,6 +215,26 @@ __global__ void __launch_bounds__(1024) frl_time_bwd_kernel(const TBArgs a) {
   TICK();
   if (a.time_embed == FRL_TEMB_FOURIER && a.g_time_kernel != nullptr) {
     // temb = [cos f, sin f], f = 2 pi t w (time_embedding.py:23-27): dL/dw[dd] = sum_j 2 pi t_j (-sin f gtemb_cos + cos f gtemb_sin)
+    if (small) {
+      // one thread per (step, frequency): the two D-long dots with MLP_0/Dense_0's rows, then a fixed-order sum over the steps
+      __syncthreads();      // s_part's previous readers are done
+      for (int i = tid; i < T * half; i += nt) {
+        const int j = i / half, dd = i - j * half;
+        double gc = 0.0, gs = 0.0;                           // dL/dtemb[j][dd], dL/dtemb[j][half + dd] = K0 dL/da1
+#pragma unroll 16
+        for (int d = 0; d < D; ++d) {
+          gc += (double)a.p.tmlp_kernel[0][(size_t)dd * D + d] * g1[j * D + d];
+          gs += (double)a.p.tmlp_kernel[0][(size_t)(half + dd) * D + d] * g1[j * D + d];
+        }
+        s_part[i] = 6.283185307179586 * tv[j] * (-temb[j * D + half + dd] * gc + temb[j * D + dd] * gs);
+      }
+      __syncthreads();
+      for (int dd = tid; dd < half; dd += nt) {
+        double s = 0.0;
+        for (int j = 0; j < T; ++j) s += s_part[j * half + dd];
+        a.g_time_kernel[dd] = (float)s;
+      }
+    } else {
     for (int dd = tid; dd < half; dd += nt) {
       double s = 0.0;
       for (int j = 0; j < T; ++j) {
@@ -227,6 +247,7 @@ __global__ void __launch_bounds__(1024) frl_time_bwd_kernel(const TBArgs a) {
         s += 6.283185307179586 * tv[j] * (-temb[j * D + half + dd] * gc + temb[j * D + dd] * gs);
       }
       a.g_time_kernel[dd] = (float)s;
+    }
     }
   }
 #ifdef FRL_TBW_PROFILE
