@@ -964,7 +964,7 @@ static int eval_bwd_plan(const FrlDesc* desc, EvalBwdPlan& q) {
   q.off_u = take((size_t)pl.B * q.Cp);
   q.off_zt = take((size_t)pl.B * pl.H);
   q.off_du = take((size_t)pl.B * q.Cp);
-  q.off_tsc = take((size_t)pl.B * (4 * D + D / 2));
+  q.off_tsc = take(time_bwd_samples_scratch_floats(pl.B, D, desc->time_embed == FRL_TEMB_FOURIER));
   q.off_ceb = take(desc->cond_embed ? (size_t)desc->n_states * 3 * COND_EMBED_DIM : 0);
   q.total_floats = o;
   return FRL_OK;

@@ -305,6 +305,14 @@ struct TimeBwdSampleArgs {
   long long B; int D, time_embed;
 };
 int launch_time_bwd_samples(const TimeBwdSampleArgs& a, hipStream_t stream);
+// The per-sample contributions are added in two fixed-order stages: chunks of TBS chunk-size samples (at most 256 chunks),
+// then the chunks in index order.  Scratch = the per-sample rows followed by [chunks][leaf elements] doubles.
+inline long long time_bwd_samples_chunk(long long B) { const long long c = (B + 255) / 256; return c < 64 ? 64 : c; }
+inline size_t time_bwd_samples_scratch_floats(long long B, int D, bool fourier) {
+  const long long S = 4 * D + D / 2, total = 2LL * D * D + 2 * D + (fourier ? D / 2 : 0);
+  const long long ch = time_bwd_samples_chunk(B), nch = (B + ch - 1) / ch;
+  return (size_t)(((B * S + 1) & ~1LL) + 2 * nch * total);
+}
 int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order second stage of the weight-gradient reduction
 
 // ---- backward, bf16-MFMA variant (csrc/sampler_bwd_bf16.hip) -------------------------------------------------

@@ -1,5 +1,5 @@
 """Wall time of one training-size chain VJP (training forward + backward from the stash), HIP events over 50 calls.
-usage: python scripts/dev/time_train_step.py [dql|dacer] [batch]"""
+usage: python scripts/dev/time_train_step.py [dql|dacer|bc] [batch]"""
 import sys
 from pathlib import Path
 
@@ -20,9 +20,14 @@ params, xT, cond, noise = H.make_inputs(case)
 model = H.product_model(case, params)
 x, c, nz = torch.from_numpy(xT).cuda(), torch.from_numpy(cond).cuda(), torch.from_numpy(noise).cuda()
 g = torch.randn(case.B, case.A, device="cuda")
+from flowrl_hip.flow.ddpm import ddpm_loss  # noqa: E402
+import flowrl_hip.random as fr  # noqa: E402
+key = fr.PRNGKey(0)
 
 
 def step():
+    if which == "bc":      # the eps-MSE loss of jit_update_ddpm with its gradients: one evaluation per sample + its VJP
+        return ddpm_loss(key, model, x, c, want_grads=True)
     _, x0, hist = model.sample(None, x, c, True, case.solver, noise=nz, params=model.params, keep_for_vjp=True)
     return model.sample_vjp(hist[0], g, c, case.solver, params=model.params, ctx=hist[2])
 
