@@ -489,6 +489,8 @@ def main():
                      "frl_sampler_fwd_train (frl_bwd_sweep_kernel<PHASE 1>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 2> + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)"
                      if stash else
                      "frl_sampler_fwd (history) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 0> [recompute + backward] + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)")
+            if stash and args.dtype == "f32" and B <= 16384:      # capi.hip lat_train_ok / sampler_bwd_lat.hip: small batches take the latency builds
+                kname = "frl_sampler_fwd_train (frl_sampler_lat_kernel<..., STASH>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_lat_kernel + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)"
             flops_exec = (3.0 if stash else 4.0) * flops_exec
             flops_alg, k_ms = 3.0 * flops_alg, f_ms + b_ms
             vjp_parts = {"forward_ms": f_ms, "backward_ms": b_ms}

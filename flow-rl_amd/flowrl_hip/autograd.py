@@ -96,6 +96,10 @@ def sample(model, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = Non
     p = params if params is not None else model.params
     flat = tree_leaves(p)
     paths = [path for path, _ in flat]
+    if not (torch.is_grad_enabled() and (xT.requires_grad or any(leaf.requires_grad for _, leaf in flat))):
+        # nothing to differentiate (an evaluation under no_grad, a target network): the plain sampler, no stash
+        rng_out, x0, hist = model.sample(rng, xT, condition, True, params=p, history=True, **kw)
+        return rng_out, x0, (hist[0], hist[1])
     x0, xh, eh, rng_out = _SampleFn.apply(model, rng, condition, dict(kw), paths, xT, *[leaf for _, leaf in flat])
     return rng_out, x0, (xh, eh)
 
@@ -124,6 +128,8 @@ def apply(model, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Ten
     _no_cond_grad(condition)
     p = params if params is not None else model.params
     flat = tree_leaves(p)
+    if not (torch.is_grad_enabled() and (x.requires_grad or any(leaf.requires_grad for _, leaf in flat))):
+        return model(x, t, condition, True, p, particles=particles)      # nothing to differentiate: the plain evaluation
     return _ApplyFn.apply(model, t, condition, particles, [path for path, _ in flat], x, *[leaf for _, leaf in flat])
 
 

@@ -208,3 +208,22 @@ def test_apply_gradient_trains():
     torch.cuda.synchronize()
     print("ag-train: eps-MSE over 13 Adam steps:", " ".join(f"{l:.4f}" for l in losses))
     assert state.step == 13 and losses[-1] < 0.8 * losses[0] and np.isfinite(losses).all()
+
+
+def test_no_grad_calls_take_the_plain_paths():
+    """Under torch.no_grad (a target network, an evaluation) fa.sample / fa.apply run the plain sampler / evaluation: same
+    return structure, no grad_fn, no stash."""
+    import torch
+    import flowrl_hip.autograd as fa
+    case = H.Case("ag-nograd", "ddpm", A=3, S=11, T=5, B=96, seed=37)
+    params, xT, cond, noise = H.make_inputs(case)
+    model = H.product_model(case, params)
+    x, c, nz = torch.from_numpy(xT).cuda(), torch.from_numpy(cond).cuda(), torch.from_numpy(noise).cuda()
+    with torch.no_grad():
+        rng, x0, (xh, eh) = fa.sample(model, None, x, c, solver="ddpm", noise=nz)
+        out = fa.apply(model, x, torch.full((case.B, 1), 3, dtype=torch.int32, device="cuda"), c)
+    _, x0_ref, (xh_ref, eh_ref) = model.sample(None, x, c, False, "ddpm", noise=nz, history=True)
+    torch.cuda.synchronize()
+    assert rng is None and x0.grad_fn is None and out.grad_fn is None
+    assert torch.equal(x0, x0_ref) and torch.equal(xh, xh_ref) and torch.equal(eh, eh_ref)
+    assert out.shape == (case.B, case.A) and torch.isfinite(out).all()
