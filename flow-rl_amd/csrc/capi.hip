@@ -500,9 +500,19 @@ static bool lat_train_ok(const KArgs& a) {
   const long long n_wt = (a.B + 31) / 32, cus = device_cus();
   return (n_wt + cus - 1) / cus <= 2 * ((n_wt + 4 * cus - 1) / (4 * cus));
 }
-static int launch_lat_train(const BArgs& b, int act, const float* wl_raw, hipStream_t stream) {
+static int launch_lat_train(const BArgs& b, int act, const float* w0_cond_rows, long long n_states, const float* wl_raw, hipStream_t stream) {
   KArgs a = b.k;
   a.stash_h = b.hd; a.stash_a = b.ad; a.wl_raw = wl_raw; a.ln_post_act = 0;
+  if (a.state_bias == nullptr && a.cond != nullptr && w0_cond_rows != nullptr && a.C > 24 && a.T >= 2) {
+    // A wide condition (DACER's 128 cond_embedding features, dacer.py:141-162) does not depend on the step: its rows of
+    // Dense_0 are contracted once per STATE (frl_state_bias_kernel) instead of 64 k-steps in every one of the T steps, and
+    // enter the kernel as a per-state accumulator init.  The rows wait in the head of the dL/dz stash region, which nothing
+    // reads or writes before the backward sweep (n_states * H <= its n_ts * L * 8192 floats).  The backward is unchanged:
+    // the dW kernel contracts the condition per chain from BArgs.dw_cond, the sweep's dL/dcfeat from its own packed image.
+    int rc = launch_state_bias(a.cond, n_states, a.C, a.H, w0_cond_rows, nullptr, b.gd, stream);
+    if (rc != FRL_OK) return rc;
+    a.state_bias = b.gd; a.C = 0; a.CK = 0;
+  }
   switch (act) {
     case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, 32, stream);
     case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, 32, stream);
@@ -606,7 +616,7 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
       a.rng_total = bufs->rng_total_chains > 0 ? bufs->rng_total_chains : pl.B;
     }
   }
-  if (!bf16 && lat_train_ok(a)) return launch_lat_train(b, desc->act, params->kernel[pl.L], stream);
+  if (!bf16 && lat_train_ok(a)) return launch_lat_train(b, desc->act, pl.C > 0 ? params->kernel[0] + (size_t)pl.c_row0 * pl.H : nullptr, desc->n_states, params->kernel[pl.L], stream);
   return bf16 ? launch_sampler_bwd_bf16(*desc, b, 1, stream) : launch_sampler_bwd(*desc, b, 1, stream);
 }
 
@@ -1049,7 +1059,7 @@ int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEv
   BArgs b;
   fill_eval_bargs(desc, params, q, ws, b);
   b.k.xT = bufs->x; b.k.x0 = bufs->out;
-  if (lat_train_ok(b.k)) return launch_lat_train(b, q.e.d.act, params->kernel[pl.L], stream);
+  if (lat_train_ok(b.k)) return launch_lat_train(b, q.e.d.act, nullptr, 0, params->kernel[pl.L], stream);
   return launch_sampler_bwd(q.e.d, b, 1, stream);
 }
 

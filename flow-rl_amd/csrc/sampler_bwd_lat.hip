@@ -31,10 +31,11 @@ __device__ __forceinline__ f32x2 ld2b(__amdgpu_buffer_rsrc_t rs, unsigned voff, 
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
 
-// DCOND (a cond_embedding, dacer.py:141-162): dL/dcfeat[chain] = sum over steps of W0[cond rows] dL/dz_0, four 32-row blocks
-// that stay in accumulators over the whole step loop (split-K partials, summed over the waves once per tile); the A
-// operands come from the packed image BArgs.ws_w0cq (frl_bwd_prepare_kernel: [4 blocks][k-step / 4][lane][4] in the one-wave
-// k-step order), where this wave's k-steps (jb, r) and (jb, r | 2) are two adjacent floats — the index map of the stash.
+// DCOND (a cond_embedding, dacer.py:141-162): dL/dcfeat[chain] = sum over steps of W0[cond rows] dL/dz_0.  The contraction
+// is linear, so this wave's dL/dz_0 features are first ADDED over the steps (32 registers) and contracted once per tile:
+// four 32-row blocks, split-K partials summed over the waves through LDS.  The A operands come from the packed image
+// BArgs.ws_w0cq (frl_bwd_prepare_kernel: [4 blocks][k-step / 4][lane][4] in the one-wave k-step order), where this wave's
+// k-steps (jb, r) and (jb, r | 2) are two adjacent floats — the index map of the stash.
 template <int NRX, bool DCOND>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_bwd_sweep_lat_kernel(const BArgs b) {
@@ -96,8 +97,8 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
     const long long chain = (long long)tile * TR + li;
     const bool valid = chain < a.B;
 
-    acc_t OC[DCOND ? 4 : 1];
-    if constexpr (DCOND) sfor<4>([&](auto MI) { sfor<NR>([&](auto RI) { OC[decltype(MI)::value][decltype(RI)::value] = 0.0f; }); });
+    f32x2 gsum[DCOND ? NBW : 1][DCOND ? NR / 2 : 1];      // sum over the steps of this wave's dL/dz_0 features (register pairs)
+    if constexpr (DCOND) sfor<NBW>([&](auto JI) { sfor<NR / 2>([&](auto MI) { gsum[decltype(JI)::value][decltype(MI)::value] = f32x2{0.0f, 0.0f}; }); });
     float gx[NRX];      // dL/dx_{j+1}, same register layout as the chain state
     sfor<NRX>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
@@ -229,27 +230,17 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
       // ================= dL/dz_0 -> stash; dL/dx_j (net part) = W0[x rows] dL/dz_0, split-K over the waves ==========
       acc_t OX;
       sfor<NR>([&](auto RI) { OX[decltype(RI)::value] = 0.0f; });
-      constexpr int NPAIR = NBW * NR / 2;      // register pairs = stash elements per lane: pair p = (jb, m)
-      f32x2 cq[DCOND ? 2 : 1][DCOND ? 4 : 1];     // cond-row operands of pairs p and p + 1 (one pair ahead)
-      auto cq_load = [&](auto PI) {
-        constexpr int p = decltype(PI)::value, jb = p / (NR / 2), m = p % (NR / 2), rp = 4 * (m >> 1) + (m & 1);
-        sfor<4>([&](auto CI) { constexpr int c = decltype(CI)::value; cq[p & 1][c] = ld2b(rs_cq, voff_cq, cq_off(c, jb, rp)); });
-      };
-      if constexpr (DCOND) cq_load(std::integral_constant<int, 0>{});
-      sfor<NPAIR>([&](auto PI) {
-        constexpr int p = decltype(PI)::value, jb = p / (NR / 2), m = p % (NR / 2), rp = 4 * (m >> 1) + (m & 1);
-        if constexpr (DCOND && p + 1 < NPAIR) cq_load(std::integral_constant<int, p + 1>{});
-        const f32x2 gz = f32x2{acc[jb][rp], acc[jb][rp + 2]} * adv[jb][m];
-        st2(gz, rs_gd, voff_st, stash_off(jb, rp));
-        OX = G::mfma(w0x[jb][rp], gz[0], OX);
-        OX = G::mfma(w0x[jb][rp + 2], gz[1], OX);
-        if constexpr (DCOND) {
-          sfor<4>([&](auto CI) {
-            constexpr int c = decltype(CI)::value;
-            OC[c] = G::mfma(cq[p & 1][c][0], gz[0], OC[c]);
-            OC[c] = G::mfma(cq[p & 1][c][1], gz[1], OC[c]);
-          });
-        }
+      sfor<NBW>([&](auto JI) {
+        constexpr int jb = decltype(JI)::value;
+        sfor<NR / 2>([&](auto MI) {
+          constexpr int m = decltype(MI)::value;
+          constexpr int rp = 4 * (m >> 1) + (m & 1);
+          const f32x2 gz = f32x2{acc[jb][rp], acc[jb][rp + 2]} * adv[jb][m];
+          st2(gz, rs_gd, voff_st, stash_off(jb, rp));
+          OX = G::mfma(w0x[jb][rp], gz[0], OX);
+          OX = G::mfma(w0x[jb][rp + 2], gz[1], OX);
+          if constexpr (DCOND) gsum[jb][m] = gsum[jb][m] + gz;
+        });
       });
       {
         float* part = s_act + (phase++ & 1) * (H * TR);
@@ -265,7 +256,26 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
       }
     }
     if constexpr (DCOND) {
-      // the four waves' partial dL/dcfeat tiles meet in LDS, one 32-row block per phase; wave m writes block m
+      // W0[cond rows] (sum over steps of dL/dz_0): operands one register pair ahead, then the four waves' partial tiles meet
+      // in LDS, one 32-row block per phase; wave m writes block m
+      constexpr int NPAIR = NBW * NR / 2;
+      acc_t OC[4];
+      sfor<4>([&](auto MI) { sfor<NR>([&](auto RI) { OC[decltype(MI)::value][decltype(RI)::value] = 0.0f; }); });
+      f32x2 cq[2][4];
+      auto cq_load = [&](auto PI) {
+        constexpr int p = decltype(PI)::value, jb = p / (NR / 2), m = p % (NR / 2), rp = 4 * (m >> 1) + (m & 1);
+        sfor<4>([&](auto CI) { constexpr int c = decltype(CI)::value; cq[p & 1][c] = ld2b(rs_cq, voff_cq, cq_off(c, jb, rp)); });
+      };
+      cq_load(std::integral_constant<int, 0>{});
+      sfor<NPAIR>([&](auto PI) {
+        constexpr int p = decltype(PI)::value, jb = p / (NR / 2), m = p % (NR / 2);
+        if constexpr (p + 1 < NPAIR) cq_load(std::integral_constant<int, p + 1>{});
+        sfor<4>([&](auto CI) {
+          constexpr int c = decltype(CI)::value;
+          OC[c] = G::mfma(cq[p & 1][c][0], gsum[jb][m][0], OC[c]);
+          OC[c] = G::mfma(cq[p & 1][c][1], gsum[jb][m][1], OC[c]);
+        });
+      });
       sfor<4>([&](auto MI) {
         constexpr int m = decltype(MI)::value;
         float* part = s_act + (phase++ & 1) * (H * TR);

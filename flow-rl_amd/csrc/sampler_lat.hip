@@ -446,7 +446,10 @@ int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
     else {
       if (a.H != 256 || !can32 || a.stash_a == nullptr || a.ws_ln != nullptr || a.NE != a.T) { set_error("latency training forward: unsupported configuration (H %d, evaluations %d / steps %d)", a.H, a.NE, a.T); return FRL_EUNSUPPORTED; }
       const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;
-      return narrow ? launch_lat_inst<32, 256, ACT, 4, 12, true>(a, ncu, stream) : launch_lat_inst<32, 256, ACT, 12, 64, true>(a, ncu, stream);
+      if (narrow) return launch_lat_inst<32, 256, ACT, 4, 12, true>(a, ncu, stream);
+      // wide x with the condition rows hoisted per state (capi.hip launch_lat_train): no 64-register cond operand array
+      if (a.C == 0) return launch_lat_inst<32, 256, ACT, 12, 1, true>(a, ncu, stream);
+      return launch_lat_inst<32, 256, ACT, 12, 64, true>(a, ncu, stream);
     }
   }
   if (use16 ? !can16 : !can32) { set_error("latency sampler: no %d-chain-tile build for this configuration (H %d, x_dim %d, operand cond rows %d)", use16 ? 16 : 32, a.H, a.A, a.C); return FRL_EUNSUPPORTED; }
