@@ -198,12 +198,14 @@ frl_cond_embed_bwd_state_kernel(int act, const float* __restrict__ obs, int S, i
   for (int k = t; k < S; k += E) s_obs[k] = obs[state * S + k];
   __syncthreads();
   float z1 = b0[t];
+#pragma unroll 8
   for (int k = 0; k < S; ++k) z1 = fmaf(s_obs[k], w0[(size_t)k * E + t], z1);
   float h1, a1;
   cact_grad(act, z1, h1, a1);
   s_h1[t] = h1;
   __syncthreads();
   float z2 = b1[t];
+#pragma unroll 16
   for (int k = 0; k < E; ++k) z2 = fmaf(s_h1[k], w1[(size_t)k * E + t], z2);
   float h2, a2;
   cact_grad(act, z2, h2, a2);
@@ -213,6 +215,7 @@ frl_cond_embed_bwd_state_kernel(int act, const float* __restrict__ obs, int S, i
   s_dz2[t] = dz2;
   __syncthreads();
   float dh1 = 0.0f;
+#pragma unroll 16
   for (int o = 0; o < E; ++o) dh1 = fmaf(w1[(size_t)t * E + o], s_dz2[o], dh1);
   float* sc = scratch + (size_t)state * 3 * E;
   sc[t] = h1;
@@ -235,15 +238,26 @@ frl_cond_embed_bwd_reduce_kernel(const float* __restrict__ obs, long long n_stat
   else if ((r -= n0) < E) { kind = 1; o = (int)r; }
   else if ((r -= E) < n1) { kind = 2; i = (int)(r / E); o = (int)(r % E); }
   else { kind = 3; o = (int)(r - n1); }
+  // state s contributes fa[s] * sc[s][ob] (fa = the observation column or h1 for the kernels, 1 for the biases), added in index
+  // order into four interleaved partial sums — 16 states' loads in flight at a time (one load per iteration left this loop at
+  // an L2 round trip per state: 90 us for 256 states)
+  const int ob = (kind <= 1) ? E + o : 2 * E + o;
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (long long s = 0; s < n_states; ++s) {
+  long long s = 0;
+  for (; s + 16 <= n_states; s += 16) {
+    float va[16], vb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float* sc = scratch + (size_t)(s + u) * 3 * E;
+      vb[u] = sc[ob];
+      va[u] = (kind == 0) ? obs[(s + u) * S + i] : (kind == 2) ? sc[i] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u & 3] += va[u] * vb[u];
+  }
+  for (; s < n_states; ++s) {
     const float* sc = scratch + (size_t)s * 3 * E;
-    float v;
-    if (kind == 0) v = obs[s * S + i] * sc[E + o];
-    else if (kind == 1) v = sc[E + o];
-    else if (kind == 2) v = sc[i] * sc[2 * E + o];
-    else v = sc[2 * E + o];
-    acc[s & 3] += v;
+    acc[s & 3] += ((kind == 0) ? obs[s * S + i] : (kind == 2) ? sc[i] : 1.0f) * sc[ob];
   }
   const float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   if (kind == 0) g_w0[e] = sum;
