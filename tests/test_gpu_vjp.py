@@ -208,15 +208,20 @@ def test_vjp_against_committed_golden():
         assert np.abs(d).max() / scale <= TOL_MAX and np.sqrt(np.mean(d * d)) / scale <= TOL_RMS, k
 
 
-def test_small_batch_training_forward_is_the_latency_build():
+@pytest.mark.parametrize("big", [
+    H.Case("lat-train-big", "ddpm", A=3, S=11, T=5, B=20000, seed=41),
+    H.Case("lat-train-big-dacer", "cddpm", A=17, S=376, T=6, B=20000, temb="learnable_fourier", schedule="cosine", cond_embed=True, seed=42),
+], ids=lambda c: c.name)
+def test_small_batch_training_forward_is_the_latency_build(big):
     """frl_sampler_fwd_train runs batches of up to 16 384 chains as the latency build with the stash kept (four waves per
     32-chain tile, csrc/sampler_lat.hip STASH; capi.hip lat_train_ok) and larger ones as the one-wave-per-tile sweep.  Every
     small case above goes through the former against the float64 oracle; here the two meet: the first 300 chains of a
     20 000-chain call (throughput sweep) and the same 300 chains alone (latency build) must give the same x0, history and
-    dL/dxT rows to float32 rounding — the stash the backward reads is laid out identically by both writers."""
+    dL/dxT rows to float32 rounding — the stash the backward reads is laid out identically by both writers.  The DACER-shape
+    case adds the wide operand build, the per-state hoist of the condition rows in the latency forward and the dL/dcfeat
+    accumulation of the latency sweep."""
     import dataclasses
     import torch
-    big = H.Case("lat-train-big", "ddpm", A=3, S=11, T=5, B=20000, seed=41)
     params, xT, cond, noise = H.make_inputs(big)
     g = np.random.default_rng(5).standard_normal((big.B, big.A)).astype(np.float32)
     model = H.product_model(big, params)
@@ -230,5 +235,6 @@ def test_small_batch_training_forward_is_the_latency_build():
     e_h = max(H.rel_err(fs["xt_hist"].cpu().numpy(), fb["xt_hist"].cpu().numpy()[:, :n]), H.rel_err(fs["eps_hist"].cpu().numpy(), fb["eps_hist"].cpu().numpy()[:, :n]))
     gb = gx_big.cpu().numpy()[:n]
     e_gx = float(np.abs(gx_small.cpu().numpy() - gb).max() / np.abs(gb).max())
-    print(f"latency vs throughput training forward: x0 {e_x0:.2e}, history {e_h:.2e}, dL/dxT rows {e_gx:.2e}")
-    assert e_x0 <= 2e-5 and e_h <= 2e-5 and e_gx <= 3e-5
+    print(f"{big.name}: latency vs throughput training forward: x0 {e_x0:.2e}, history {e_h:.2e}, dL/dxT rows {e_gx:.2e}")
+    tol = 2e-5 if big.kind == "ddpm" else 1e-4      # the continuous chain divides by sqrt(alpha_hat) down to 0.08
+    assert e_x0 <= tol and e_h <= tol and e_gx <= 1.5 * tol
