@@ -514,12 +514,12 @@ static int launch_lat_train(const BArgs& b, int act, const float* w0_cond_rows, 
     a.state_bias = b.gd; a.C = 0; a.CK = 0;
   }
   switch (act) {
-    case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, 32, stream);
-    case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, 32, stream);
-    case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, 32, stream);
-    case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, 32, stream);
-    case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, 32, stream);
-    default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, 32, stream);
+    case FRL_ACT_MISH: return launch_sampler_lat_act<FRL_ACT_MISH>(a, 0, stream);
+    case FRL_ACT_SILU: return launch_sampler_lat_act<FRL_ACT_SILU>(a, 0, stream);
+    case FRL_ACT_RELU: return launch_sampler_lat_act<FRL_ACT_RELU>(a, 0, stream);
+    case FRL_ACT_GELU_TANH: return launch_sampler_lat_act<FRL_ACT_GELU_TANH>(a, 0, stream);
+    case FRL_ACT_TANH: return launch_sampler_lat_act<FRL_ACT_TANH>(a, 0, stream);
+    default: return launch_sampler_lat_act<FRL_ACT_ELU>(a, 0, stream);
   }
 }
 

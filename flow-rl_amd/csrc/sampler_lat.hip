@@ -47,7 +47,10 @@ template <> struct WVec<4> {
 template <int TR, int H, int ACT, int NRX, int CKMAX, bool STASH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_lat_kernel(const KArgs a) {
-  static_assert(!STASH || (TR == 32 && H == 256), "the stash layout is the 32-chain, 256-wide one");
+  static_assert(!STASH || H == 256, "the stash layout is the 256-wide one");
+  // 16-chain tiles (TR = 16) write the SAME 32-chain stash blocks: tile t is chains 16 (t & 1) .. + 15 of wave-tile t >> 1, and
+  // register (jb, r) of lane (li, ls) — feature 64 w + 4 (r + 4 ls) + jb — sits at k-step 16 (4 (w >> 1) + jb) + r + 8 (w & 1)
+  // + 4 (ls >> 1) of lane 16 (t & 1) + li + 32 (ls & 1): registers r and r + 1 (r even) are one 8-byte element.
   typedef Geo<TR> G;                // 32: MFMA 32x32x2, 16: MFMA 16x16x4 (tiles of 16 chains: half the latency again)
   typedef typename G::acc_t acc_t;
   constexpr int NR = G::NR, KS = G::KS;
@@ -96,8 +99,12 @@ frl_sampler_lat_kernel(const KArgs a) {
   const unsigned voff_h = ls * ROWB + voff_col;         // hidden / cond rows: k-step's row 2 ks + ls
   const unsigned voff_x = ls * (4 * ROWB) + voff_col;   // Dense_0 x rows: ROWR(n) + 4 ls
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws_w0p, 0, a.w0p_bytes, 0x00020000);
-  const unsigned voff_st = (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + ls) * 512 + li * 8;   // STASH: this lane's part of the element address
-  auto stash_off = [](int jb, int rp) { return (16 * (rp & 1) + 8 * jb + 2 * (rp >> 3)) * 512 + 256 * ((rp >> 2) & 1); };   // rp: bit 1 clear
+  // STASH: this lane's part of the element address (16-chain tiles add 128 bytes for the odd tile of a pair, below)
+  const unsigned voff_st0 = (TR == 32) ? (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + ls) * 512 + li * 8
+                                       : (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + 2 * (ls >> 1)) * 512 + (li + 32 * (ls & 1)) * 8;
+  // the first register rp of a pair -> compile-time part of the address; its partner is rp + 2 (TR 32) or rp + 1 (TR 16)
+  auto stash_off = [](int jb, int rp) { return TR == 32 ? (16 * (rp & 1) + 8 * jb + 2 * (rp >> 3)) * 512 + 256 * ((rp >> 2) & 1) : (8 * jb + (rp >> 1)) * 512; };
+  constexpr int PSTEP = (TR == 32) ? 2 : 1;
 
   // Dense_L operands stay resident: k-step (jb, r) contracts feature FW w + NBW (ROWR(r) + 4 ls) + jb, lane i = output row
   float wl[NBW][NR];
@@ -113,7 +120,8 @@ frl_sampler_lat_kernel(const KArgs a) {
     });
   }
 
-  const int ntiles = (int)((a.B + TR - 1) / TR);
+  // (STASH on 16-chain tiles: both halves of the last wave-tile are run, so that every stash row holds finite values)
+  const int ntiles = (STASH && TR == 16) ? 2 * (int)((a.B + 31) / 32) : (int)((a.B + TR - 1) / TR);
   // Dense_0 operands never depend on the data: the first R0 - 1 k-steps of the NEXT evaluation are requested before
   // Dense_L and the epilogue of the current one (and before the first tile here)
   wv_t r0[R0];
@@ -152,7 +160,8 @@ frl_sampler_lat_kernel(const KArgs a) {
 
     for (int j = 0; j < a.NE; ++j) {
       acc_t acc[NBW];
-      const size_t srow = STASH ? ((size_t)tile * a.NE + j) * a.L * 8192 : 0;      // floats: this tile-step's L stash blocks
+      const size_t srow = STASH ? ((size_t)(TR == 32 ? tile : tile >> 1) * a.NE + j) * a.L * 8192 : 0;      // floats: this tile-step's L stash blocks
+      const unsigned voff_st = voff_st0 + ((TR == 16) ? (unsigned)(tile & 1) * 128 : 0u);
       const __amdgpu_buffer_rsrc_t rs_hd = __builtin_amdgcn_make_buffer_rsrc((void*)(STASH ? a.stash_h + srow : nullptr), 0, STASH ? a.L * 32768 : 0, 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(STASH ? a.stash_a + srow : nullptr), 0, STASH ? a.L * 32768 : 0, 0x00020000);
       // ---------------- Dense_0 ------------------------------------------------------------------------
@@ -259,11 +268,12 @@ frl_sampler_lat_kernel(const KArgs a) {
               if constexpr (STASH) {
                 sfor<2>([&](auto EI) {
                   constexpr int e = decltype(EI)::value;
+                  constexpr int e0 = (TR == 32) ? e : 2 * e, e1 = e0 + PSTEP;      // the pair's places in this group of four
                   f32x2 h, d;
-                  act_grad2<ACT>(f32x2{acc[jb][4 * q + e], acc[jb][4 * q + e + 2]}, h, d);
-                  v[e] = h[0]; v[e + 2] = h[1];
-                  st2(h, rs_hd, voff_st, (l - 1) * 32768 + stash_off(jb, 4 * q + e));
-                  st2(d, rs_ad, voff_st, (l - 1) * 32768 + stash_off(jb, 4 * q + e));
+                  act_grad2<ACT>(f32x2{acc[jb][4 * q + e0], acc[jb][4 * q + e1]}, h, d);
+                  v[e0] = h[0]; v[e1] = h[1];
+                  st2(h, rs_hd, voff_st, (l - 1) * 32768 + stash_off(jb, 4 * q + e0));
+                  st2(d, rs_ad, voff_st, (l - 1) * 32768 + stash_off(jb, 4 * q + e0));
                 });
               } else {
                 sfor<4>([&](auto EI) { constexpr int e = decltype(EI)::value; v[e] = act_fn<ACT>(acc[jb][4 * q + e]); });
@@ -312,13 +322,13 @@ frl_sampler_lat_kernel(const KArgs a) {
           constexpr int jb = decltype(JI)::value;
           sfor<NR / 2>([&](auto MI) {
             constexpr int m = decltype(MI)::value;
-            constexpr int rp = 4 * (m >> 1) + (m & 1);      // registers rp and rp | 2 share a stash element
+            constexpr int rp = (TR == 32) ? 4 * (m >> 1) + (m & 1) : 2 * m;      // registers rp and rp + PSTEP share a stash element
             f32x2 h, d;
-            act_grad2<ACT>(f32x2{acc[jb][rp], acc[jb][rp + 2]}, h, d);
+            act_grad2<ACT>(f32x2{acc[jb][rp], acc[jb][rp + PSTEP]}, h, d);
             st2(h, rs_hd, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
             st2(d, rs_ad, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
             O = G::mfma(wl[jb][rp], h[0], O);
-            O = G::mfma(wl[jb][rp + 2], h[1], O);
+            O = G::mfma(wl[jb][rp + PSTEP], h[1], O);
           });
         });
       } else {
@@ -419,7 +429,7 @@ static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
   auto kern = frl_sampler_lat_kernel<TR, H, ACT, NRX, CKMAX, STASH>;
   a.AR = 4 * ((a.A + 4 * Geo<TR>::KS - 1) / (4 * Geo<TR>::KS));   // x k-steps: four of them contract 4 KS rows (ROWR(n) + 4 s)
   a.CK = (a.C + Geo<TR>::KS - 1) / Geo<TR>::KS;
-  const long long ntiles = (a.B + TR - 1) / TR;
+  const long long ntiles = (STASH && TR == 16) ? 2 * ((a.B + 31) / 32) : (a.B + TR - 1) / TR;
   const int grid = (int)(ntiles < 4LL * ncu ? ntiles : 4LL * ncu);
   const bool ln = a.ws_ln != nullptr;
   a.lat_tb_global = lat_lds_bytes(a.NE, a.L, H, true, ln) > 160 * 1024 ? 1 : 0;
@@ -445,6 +455,9 @@ int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
     if constexpr (ACT == FRL_ACT_IDENTITY) { set_error("latency training forward: no identity-activation unit"); return FRL_EINVAL; }
     else {
       if (a.H != 256 || !can32 || a.stash_a == nullptr || a.ws_ln != nullptr || a.NE != a.T) { set_error("latency training forward: unsupported configuration (H %d, evaluations %d / steps %d)", a.H, a.NE, a.T); return FRL_EUNSUPPORTED; }
+      // 16-chain tiles while they still give every CU at most one tile (the forward's own rule): half the latency per tile
+      if (tile_rows != 32 && can16 && 2 * ((a.B + 31) / 32) <= ncu)
+        return (a.C + 3) / 4 <= 12 ? launch_lat_inst<16, 256, ACT, 4, 12, true>(a, ncu, stream) : launch_lat_inst<16, 256, ACT, 4, 32, true>(a, ncu, stream);
       const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;
       if (narrow) return launch_lat_inst<32, 256, ACT, 4, 12, true>(a, ncu, stream);
       // wide x with the condition rows hoisted per state (capi.hip launch_lat_train): no 64-register cond operand array
