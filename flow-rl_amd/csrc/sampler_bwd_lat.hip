@@ -36,18 +36,23 @@ __device__ __forceinline__ f32x2 ld2b(__amdgpu_buffer_rsrc_t rs, unsigned voff, 
 // four 32-row blocks, split-K partials summed over the waves through LDS.  The A operands come from the packed image
 // BArgs.ws_w0cq (frl_bwd_prepare_kernel: [4 blocks][k-step / 4][lane][4] in the one-wave k-step order), where this wave's
 // k-steps (jb, r) and (jb, r | 2) are two adjacent floats — the index map of the stash.
-template <int NRX, bool DCOND>
+// TR = 16 (MFMA 16x16x4): tiles of 16 chains — half the latency per tile while every CU still gets at most one — on the SAME
+// 32-chain stash blocks: tile t is chains 16 (t & 1) .. + 15 of wave-tile t >> 1 (sampler_lat.hip STASH has the index map:
+// register (jb, r) of lane (li, ls) at k-step 16 (4 (w >> 1) + jb) + r + 8 (w & 1) + 4 (ls >> 1), lane 16 (t & 1) + li + 32 (ls & 1)).
+template <int TR, int NRX, bool DCOND>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_bwd_sweep_lat_kernel(const BArgs b) {
-  typedef Geo<32> G;
+  typedef Geo<TR> G;
   typedef typename G::acc_t acc_t;
-  constexpr int TR = 32, H = 256, NR = G::NR, KS = G::KS;
-  constexpr int NBW = H / (4 * TR);   // 2 output blocks per wave
+  static_assert(TR == 32 || (TR == 16 && !DCOND && NRX == 4), "16-chain tiles: x_dim <= 16, no dL/dcfeat");
+  constexpr int H = 256, NR = G::NR, KS = G::KS;
+  constexpr int NBW = H / (4 * TR);   // 2 (TR 32) or 4 (TR 16) output blocks per wave
   constexpr int FW = H / 4;           // 64 features per wave
   constexpr int NK = H / KS;          // 128 k-steps per hidden layer
   constexpr int ROWB = H * 4;
-  constexpr int RW = 16;              // hidden-layer weight ring (k-steps ahead)
-  constexpr int NP = NBW * NR / 2;    // stash elements (register pairs) per lane and layer
+  constexpr int RW = (TR == 16) ? 32 : 16;   // hidden-layer weight ring (k-steps ahead), as in the forward latency kernel
+  constexpr int PSTEP = (TR == 32) ? 2 : 1;  // registers rp and rp + PSTEP are the two floats of one stash element
+  auto pair_reg = [](int m) { return TR == 32 ? 4 * (m >> 1) + (m & 1) : 2 * m; };   // first register of pair m
   static_assert(NBW == KS && NK % RW == 0, "geometry");
   const KArgs& a = b.k;
 
@@ -65,8 +70,9 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
   const unsigned voff_col = (unsigned)(FW * wave + NBW * li) * 4;
   const unsigned voff_h = ls * ROWB + voff_col;         // transposed hidden kernels: k-step's row 2 ks + ls, this wave's columns
   const unsigned voff_x = ls * (4 * ROWB) + voff_col;   // W_L^T rows ROWR(n) + 4 ls
-  const unsigned voff_st = (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + ls) * 512 + li * 8;   // stash element address, per-lane part
-  auto stash_off = [](int jb, int rp) { return (16 * (rp & 1) + 8 * jb + 2 * (rp >> 3)) * 512 + 256 * ((rp >> 2) & 1); };   // rp: bit 1 clear
+  const unsigned voff_st0 = (TR == 32) ? (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + ls) * 512 + li * 8      // stash element address, per-lane part
+                                       : (unsigned)(32 * (wave >> 1) + 4 * (wave & 1) + 2 * (ls >> 1)) * 512 + (li + 32 * (ls & 1)) * 8;
+  auto stash_off = [](int jb, int rp) { return TR == 32 ? (16 * (rp & 1) + 8 * jb + 2 * (rp >> 3)) * 512 + 256 * ((rp >> 2) & 1) : (8 * jb + (rp >> 1)) * 512; };
   const __amdgpu_buffer_rsrc_t rs_wlt = __builtin_amdgcn_make_buffer_rsrc((void*)b.ws_wlt, 0, a.XR * ROWB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_cq = __builtin_amdgcn_make_buffer_rsrc((void*)(DCOND ? b.ws_w0cq : b.ws_wlt), 0, DCOND ? 4 * H * 64 * 4 : 0, 0x00020000);
   const unsigned voff_cq = (unsigned)((16 * (wave >> 1) + 2 * (wave & 1)) * 256 + li * 4 + 2 * ls) * 4;
@@ -83,15 +89,18 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
     });
   });
 
-  typedef f32x2 wv_t;
-  auto wld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) { return ld2b(rs, voff, soff); };
+  typedef typename std::conditional<TR == 32, f32x2, f32x4>::type wv_t;      // NBW floats: this lane's columns of one weight row
+  auto wld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) -> wv_t {
+    if constexpr (TR == 32) return ld2b(rs, voff, soff);
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  };
   wv_t ring[RW];
   if (a.L > 1) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(b.wt, a.L - 2), 0, H * ROWB, 0x00020000);
     sfor<RW - 1>([&](auto KI) { constexpr int k = decltype(KI)::value; ring[k] = wld(rs1, voff_h, KS * k * ROWB); });
   }
 
-  const int ntiles = (int)((a.B + TR - 1) / TR);
+  const int ntiles = (TR == 16) ? 2 * (int)((a.B + 31) / 32) : (int)((a.B + TR - 1) / TR);   // (16: both halves of the last wave-tile, so that every dL/dz row is written)
   int phase = 0;   // LDS buffer parity, runs on across layers, steps and tiles
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long chain = (long long)tile * TR + li;
@@ -108,8 +117,9 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
 
     for (int jj = 0; jj < a.T; ++jj) {
       const int j = a.T - 1 - jj;
-      const long long ts = (long long)tile * a.T + j;
+      const long long ts = (long long)(TR == 32 ? tile : tile >> 1) * a.T + j;
       const size_t srow = (size_t)ts * a.L * 8192;
+      const unsigned voff_st = voff_st0 + ((TR == 16) ? (unsigned)(tile & 1) * 128 : 0u);
       const __amdgpu_buffer_rsrc_t rs_ad = __builtin_amdgcn_make_buffer_rsrc((void*)(b.ad + srow), 0, a.L * 32768, 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_gd = __builtin_amdgcn_make_buffer_rsrc((void*)(b.gd + srow), 0, a.L * 32768, 0x00020000);
 
@@ -120,7 +130,7 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
           constexpr int jb = decltype(JI)::value;
           sfor<NR / 2>([&](auto MI) {
             constexpr int m = decltype(MI)::value;
-            adv[jb][m] = ld2b(rs_ad, voff_st, l * 32768 + stash_off(jb, 4 * (m >> 1) + (m & 1)));
+            adv[jb][m] = ld2b(rs_ad, voff_st, l * 32768 + stash_off(jb, pair_reg(m)));
           });
         });
       };
@@ -174,7 +184,18 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
         const bool in = valid && ai < a.A;
         ge[r] = in ? g_e : 0.0f;
         gxd[r] = in ? g_x : 0.0f;
-        if (wave == 0) b.ge[(size_t)ts * b.ge_stride + r * 64 + lane] = ge[r];
+        if (wave == 0) {
+          if constexpr (TR == 32) b.ge[(size_t)ts * b.ge_stride + r * 64 + lane] = ge[r];
+          else {      // action row r + 4 ls of chain 16 (t & 1) + li: register r + 4 (ls >> 1), lane half ls & 1 of the one-wave layout
+            const int r32 = r + 4 * (ls >> 1);
+            if (r32 < (b.ge_stride >> 6)) b.ge[(size_t)ts * b.ge_stride + r32 * 64 + 16 * (tile & 1) + li + 32 * (ls & 1)] = ge[r];
+            // the wide stash also has registers 8 .. 11 (action rows 16 .. 23: none here), which the dW kernel reads: zeros
+            if (r == 0 && (b.ge_stride >> 6) > 8) {
+              b.ge[(size_t)ts * b.ge_stride + (8 + ls) * 64 + 16 * (tile & 1) + li] = 0.0f;
+              b.ge[(size_t)ts * b.ge_stride + (8 + ls) * 64 + 16 * (tile & 1) + li + 32] = 0.0f;
+            }
+          }
+        }
       });
 
       // ================= dL/dh_{L-1} = W_L dL/deps: this wave's 64 features ====================================
@@ -203,9 +224,10 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
             f32x4 v;
             sfor<2>([&](auto EI) {
               constexpr int e = decltype(EI)::value;
-              const f32x2 gz = f32x2{acc[jb][4 * q + e], acc[jb][4 * q + e + 2]} * adv[jb][2 * q + e];
-              st2(gz, rs_gd, voff_st, l * 32768 + stash_off(jb, 4 * q + e));
-              v[e] = gz[0]; v[e + 2] = gz[1];
+              constexpr int e0 = (TR == 32) ? e : 2 * e, e1 = e0 + PSTEP;      // the pair's places in this group of four
+              const f32x2 gz = f32x2{acc[jb][4 * q + e0], acc[jb][4 * q + e1]} * adv[jb][2 * q + e];
+              st2(gz, rs_gd, voff_st, l * 32768 + stash_off(jb, 4 * q + e0));
+              v[e0] = gz[0]; v[e1] = gz[1];
             });
             *(f32x4*)(abuf + (((ks >> 2) * 64) + jb * TR + li) * 4) = v;
           });
@@ -234,11 +256,11 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
         constexpr int jb = decltype(JI)::value;
         sfor<NR / 2>([&](auto MI) {
           constexpr int m = decltype(MI)::value;
-          constexpr int rp = 4 * (m >> 1) + (m & 1);
-          const f32x2 gz = f32x2{acc[jb][rp], acc[jb][rp + 2]} * adv[jb][m];
+          constexpr int rp = (TR == 32) ? 4 * (m >> 1) + (m & 1) : 2 * m;
+          const f32x2 gz = f32x2{acc[jb][rp], acc[jb][rp + PSTEP]} * adv[jb][m];
           st2(gz, rs_gd, voff_st, stash_off(jb, rp));
           OX = G::mfma(w0x[jb][rp], gz[0], OX);
-          OX = G::mfma(w0x[jb][rp + 2], gz[1], OX);
+          OX = G::mfma(w0x[jb][rp + PSTEP], gz[1], OX);
           if constexpr (DCOND) gsum[jb][m] = gsum[jb][m] + gz;
         });
       });
@@ -301,11 +323,11 @@ frl_bwd_sweep_lat_kernel(const BArgs b) {
   }
 }
 
-template <int NRX, bool DCOND>
+template <int TR, int NRX, bool DCOND>
 int launch_inst(const BArgs& b, hipStream_t stream) {
-  auto kern = frl_bwd_sweep_lat_kernel<NRX, DCOND>;
+  auto kern = frl_bwd_sweep_lat_kernel<TR, NRX, DCOND>;
   const KArgs& a = b.k;
-  const long long ntiles = (a.B + 31) / 32;
+  const long long ntiles = (TR == 16) ? 2 * ((a.B + 31) / 32) : (a.B + 31) / 32;
   const int ncu = device_cus();
   const int grid = (int)(ntiles < 4LL * ncu ? ntiles : 4LL * ncu);
   const size_t lds = sizeof(float) * ((size_t)a.T * COEF_STRIDE + 2 * 256 * 32);
@@ -334,9 +356,11 @@ int launch_bwd_sweep_lat(const BArgs& b, hipStream_t stream) {
   // the dL/deps stash holds ge_stride / 64 registers per lane (4 | 12: BwdPlan.wide), all of which the dW kernel reads
   if (b.gcf != nullptr) {      // a cond_embedding always takes the wide operand build (128 condition rows)
     if ((b.ge_stride >> 6) <= 4) { set_error("latency backward sweep: dL/dcfeat with the narrow dL/deps stash"); return FRL_EINVAL; }
-    return launch_inst<12, true>(b, stream);
+    return launch_inst<32, 12, true>(b, stream);
   }
-  return (b.ge_stride >> 6) <= 4 ? launch_inst<4, false>(b, stream) : launch_inst<12, false>(b, stream);
+  // 16-chain tiles while every CU still gets at most one tile (x_dim <= 16; the narrow dL/deps stash holds 8 action rows)
+  if (b.k.A <= ((b.ge_stride >> 6) <= 4 ? 8 : 16) && 2 * ((b.k.B + 31) / 32) <= device_cus()) return launch_inst<16, 4, false>(b, stream);
+  return (b.ge_stride >> 6) <= 4 ? launch_inst<32, 4, false>(b, stream) : launch_inst<32, 12, false>(b, stream);
 }
 
 }  // namespace frl
