@@ -137,9 +137,14 @@ def vjp_parts_ms(model, w, xT, cond, noise, g, iters):
     def bwd(hist):
         model.sample_vjp(hist[0], g, cond, "ddpm", want_gxT=False, compute_dtype=cd, ctx=hist[2] if stash else None)
 
+    from flowrl_hip import _lib
+    lib = _lib.load()
     hist = fwd()
+    names = [lib.frl_last_kernels().decode()]
     for _ in range(2):
         bwd(hist)
+    names.append(lib.frl_last_kernels().decode())
+    vjp_parts_ms.kernels = "forward call: " + names[0] + " | backward call: " + names[1]
     out = []
     for fn in (fwd, lambda: bwd(hist)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -212,6 +217,9 @@ def kernel_only_ms(model, w, xT, cond, noise, iters):
     kernel_only_ms.hoisted = lib.frl_hoisted_flops(C.byref(desc))
     return e0.elapsed_time(e1) / iters, flops_alg - kernel_only_ms.hoisted, flops_exec.value
 
+
+# --scaling strong: the job-wide number of STATES; workloads not listed keep their per-GPU batch as the total
+STRONG_TOTAL_STATES = {"cfg3": 8388608, "cfg4": 65536}
 
 # committed rocprofv3 PMC passes (scripts/prof_r2.sh) per workload at its full batch: (summary file, sampler kernel name)
 TRAFFIC_PROFILES = {
@@ -311,13 +319,32 @@ def launch_ranks(n: int, argv, stub: bool) -> int:
                    MASTER_PORT=str(port), FRL_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    # rank 0's stdout is drained by a thread; the parent polls EVERY child, so that the early death of any rank ends the
+    # run at once (the others would otherwise sit in the rendezvous until its timeout)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    bad = []
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.05)
     if bad:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
         print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr, flush=True)
-        return next(rc for _, rc in bad) or 1
-    sys.stdout.write(out0)
+        return bad[0][1] or 1
+    reader.join(timeout=10)
+    sys.stdout.write("".join(chunks))
     sys.stdout.flush()
     return 0
 
@@ -371,6 +398,10 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
     ap.add_argument("--recompute", action="store_true", help="cfg5: plain forward with history + a backward that recomputes every step (round-1 path) instead of the training forward's stash")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU / gloo stand-in of the rank body (no GPU, not a measurement)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank owns the workload's per-GPU batch; strong: the workload's TOTAL batch (SURVEY 8(d): cfg4 = "
+                         "65536 states x 64 particles, cfg3 = 8388608 chains; others: the per-GPU batch) is split over the ranks by state index "
+                         "(flowrl_hip.parallel.shard_bounds)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -403,6 +434,16 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         w["B"] = args.batch
+    total_chains = None
+    if args.scaling == "strong":
+        # the job's size is fixed; rank r owns the contiguous block of states shard_bounds gives it (a state's particles
+        # stay together), ragged when the total does not divide
+        from flowrl_hip import parallel as _par
+        total_states = STRONG_TOTAL_STATES.get(args.workload, WORKLOADS[args.workload]["B"] // w["particles"]) if args.batch <= 0 else args.batch // w["particles"]
+        lo, hi = _par.shard_bounds(total_states, rank, world)
+        w["B"] = (hi - lo) * w["particles"]
+        total_chains = total_states * w["particles"]
+        shard_counts = [(_par.shard_bounds(total_states, r, world)[1] - _par.shard_bounds(total_states, r, world)[0]) * w["particles"] for r in range(world)]
     w["dtype"] = args.dtype
     w["tile_policy"] = args.tile_policy
     w["rng"] = args.rng
@@ -422,12 +463,12 @@ def main():
                           "exec_tflops": fe / k_ms / 1e9}))
         return
     xT, cond, noise = make_inputs(w, dev, 1234 + rank)       # this rank's shard of the states
-    gathered = torch.empty((world * B, A), device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, A), device=dev) if (world > 1 and total_chains is None) else None
     if world > 1 and args.rng != "none":
-        w["rng_shard"] = (rank * B, world * B)
+        w["rng_shard"] = (rank * B, world * B) if total_chains is None else (sum(shard_counts[:rank]), total_chains)
 
     vjp = bool(w.get("vjp"))
-    g_x0 = torch.randn((B, A), generator=torch.Generator(device=dev).manual_seed(99 + rank), device=dev) / (world * B) if vjp else None
+    g_x0 = torch.randn((B, A), generator=torch.Generator(device=dev).manual_seed(99 + rank), device=dev) / (total_chains if total_chains is not None else world * B) if vjp else None
 
     def step():
         if vjp:
@@ -438,7 +479,11 @@ def main():
             return x0
         x0 = sample(model, w, xT, cond, noise)
         if world > 1 and not args.no_gather:
-            dist.all_gather_into_tensor(gathered, x0)
+            if total_chains is None:
+                dist.all_gather_into_tensor(gathered, x0)
+            else:
+                from flowrl_hip import parallel
+                parallel.all_gather_ragged(x0, shard_counts)
         return x0
 
     def fence():
@@ -461,50 +506,32 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(x0).all()
     ms_per_step = dt / args.steps * 1e3
-    value = world * B * T / (dt / args.steps)
+    job_chains = total_chains if total_chains is not None else world * B
+    value = job_chains * T / (dt / args.steps)
 
     out = None
     if rank == 0:
         k_ms, flops_alg, flops_exec = kernel_only_ms(model, w, xT, cond, noise, max(5, args.steps))
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        lat = args.tile_policy.startswith("latency") or (args.tile_policy == "auto" and (B + 15) // 16 <= ncu) or (args.tile_policy == "auto" and -(-((B + 31) // 32) // ncu) <= 3 * -(-((B + 31) // 32) // (4 * ncu)))
-        kname = "frl_sampler_lat_kernel" if (lat and args.dtype == "f32") else "frl_sampler_rs_kernel"
-        # plan_two_wave (csrc/frl_internal.h): big plain 256-wide f32 batches run the 16-chain geometry at two waves per SIMD
-        c_op = 128 if w["cond_embed"] else w["S"]
-        if (kname == "frl_sampler_rs_kernel" and args.dtype == "f32" and w.get("backbone", "mlp") == "mlp" and not w.get("ln")
-                and all(h == 256 for h in w["hidden"]) and args.rng == "none" and args.tile_policy in ("auto", "throughput")
-                and w["A"] <= 16 and c_op <= 48 and not (w["particles"] >= 4 and c_op >= 32) and B >= 65536 and not vjp
-                and getattr(args, "solver", None) in (None, "ddpm", "ddim")):
-            kname = "frl_sampler_rs_kernel_w2"
-        if w.get("backbone", "mlp") != "mlp":
-            kname = "frl_sampler_res_kernel"
+        # the library names the kernels its last call enqueued (frl_last_kernels: written by the launchers themselves)
+        from flowrl_hip import _lib as _flib
+        kname = _flib.load().frl_last_kernels().decode()
         if vjp:
             # FLOPs_alg,bwd = 2 x forward (dX + dW); the sweep's forward recompute is overhead, not credit
             f_ms, b_ms = vjp_parts_ms(model, w, xT, cond, noise, g_x0, max(5, args.steps))
             stash = not args.recompute
-            kname = (("frl_sampler_fwd_train (frl_bwd_sweep_bf16_kernel<PHASE 1>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel<PHASE 2> + frl_bwd_dw_bf16_kernel + frl_bwd_reduce_kernel)"
-                      if stash else
-                      "frl_sampler_fwd (bf16, history) + frl_sampler_bwd call (frl_bwd_sweep_bf16_kernel<PHASE 0> [recompute + backward] + frl_bwd_dw_bf16_kernel + frl_bwd_reduce_kernel)")
-                     if args.dtype == "bf16" else
-                     "frl_sampler_fwd_train (frl_bwd_sweep_kernel<PHASE 1>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 2> + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)"
-                     if stash else
-                     "frl_sampler_fwd (history) + frl_sampler_bwd call (frl_bwd_sweep_kernel<PHASE 0> [recompute + backward] + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)")
-            if stash and args.dtype == "f32" and B <= 16384:      # capi.hip lat_train_ok / sampler_bwd_lat.hip: small batches take the latency builds
-                kname = "frl_sampler_fwd_train (frl_sampler_lat_kernel<..., STASH>: forward + stash) + frl_sampler_bwd call (frl_bwd_sweep_lat_kernel + frl_bwd_dw_kernel + frl_bwd_reduce_kernel)"
+            kname = vjp_parts_ms.kernels
             flops_exec = (3.0 if stash else 4.0) * flops_exec
             flops_alg, k_ms = 3.0 * flops_alg, f_ms + b_ms
             vjp_parts = {"forward_ms": f_ms, "backward_ms": b_ms}
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
         traffic, traffic_src = (None, None) if (vjp or args.act or args.layers or args.dtype != "f32" or args.rng != "none" or args.tile_policy != "auto") else pmc_traffic_bytes(args.workload, w)
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        if args.dtype == "bf16" and not vjp:
-            kname = "frl_sampler_bf16_kernel"
         out = {
             "metric": "action samples/sec x T steps (chain-steps/s), fused sampler",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {w['desc']}", "chains_per_gpu": B, "T": T,
+            "config": {"workload": f"{args.workload}: {w['desc']}" + (f" [strong scaling: {job_chains} chains in total, {B} on rank 0]" if total_chains is not None else ""), "chains_per_gpu": B, "T": T,
                        "chains_per_s": value / T, "prepare": "cached across calls" if args.cache_prepare else "every call", "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,

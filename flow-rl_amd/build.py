@@ -80,6 +80,15 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> Path:
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    # the torch-free driver (bench/native_bench.cpp): host code against include/flowrl_hip.h + RCCL, finds the library
+    # next to the package through its rpath
+    nb_src, nb_out = ROOT / "bench" / "native_bench.cpp", ROOT / "bench" / "native_bench"
+    if nb_src.exists() and (force or _stale(nb_out, [nb_src, ROOT / "include" / "flowrl_hip.h", OUT])):
+        cmd = [cc, "-O2", "-std=c++17", str(nb_src), f"-I{ROOT / 'include'}", f"-L{OUT.parent}", "-lflowrl_hip", "-lrccl",
+               "-Wl,-rpath,$ORIGIN/../flow-rl_amd/flowrl_hip", "-o", str(nb_out)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return OUT
 
 

@@ -46,6 +46,19 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kern[1024] = "";
+static void clear_kernels() { g_kern[0] = 0; }
+void note_kernel(const char* fmt, ...) {
+  const size_t n = strlen(g_kern);
+  if (n + 4 >= sizeof(g_kern)) return;
+  size_t o = n;
+  if (n > 0) { memcpy(g_kern + n, " + ", 3); o = n + 3; }
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kern + o, sizeof(g_kern) - o, fmt, ap);
+  va_end(ap);
+}
+
 // f32 network kernel dispatch: latency build for small batches, throughput build otherwise
 static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStream_t stream) {
   if (a.ln_post_act != 0) act = FRL_ACT_IDENTITY_BUILD;     // post-activation LayerNorm: the pass applies the activation itself
@@ -228,6 +241,8 @@ int frl_abi_version(void) { return FRL_ABI_VERSION; }
 
 const char* frl_last_error(void) { return g_err; }
 
+const char* frl_last_kernels(void) { return g_kern; }
+
 int frl_validate(const FrlDesc* desc) { return validate_desc(desc); }
 
 size_t frl_workspace_bytes(const FrlDesc* desc) {
@@ -250,7 +265,7 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     if (executed != nullptr) {
       Plan pl;
       plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
-      *executed = 2.0 * B * T * ((double)pl.XR * H + desc->n_hidden * blk + H * LAST_PAD) + cf + 2.0 * (double)desc->n_states * C * H;
+      *executed = 2.0 * B * T * ((double)pl.XR * H + desc->n_hidden * blk + H * pl.TR) + cf + 2.0 * (double)desc->n_states * C * H;
     }
     return 2.0 * B * T * (macs + desc->n_hidden * blk + H * A) + cf;
   }
@@ -262,7 +277,7 @@ double frl_algorithmic_flops(const FrlDesc* desc, double* executed) {
     plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
     double em = (double)(pl.XR + pl.KS * pl.CK) * pl.H;         // Dense_0 without the hoisted time slice, padded
     for (int l = 1; l < desc->n_hidden; ++l) em += (double)desc->hidden[l - 1] * desc->hidden[l];
-    em += (double)pl.H * LAST_PAD;                                // Dense_L padded to one MFMA block
+    em += (double)pl.H * pl.TR;                                   // Dense_L padded to one MFMA block (32 or 16 rows: the geometry the plan picks)
     if (pl.bf16) em += (double)(16 * (pl.bf_nxk + pl.bf_cks) - (pl.XR + pl.KS * pl.CK)) * pl.H;   // bf16: 16-wide k-steps
     *executed = 2.0 * B * T * em + cond_flops + (pl.hoist ? 2.0 * (double)desc->n_states * pl.C * pl.H : 0.0);   // hoisted cond rows: once per state
   }
@@ -278,13 +293,22 @@ double frl_hoisted_flops(const FrlDesc* desc) {
   return 2.0 * (evals - (double)desc->n_states) * pl.C * pl.H;
 }
 
+// both_regions: a descriptor whose workspace holds the 32-chain AND the 16-chain geometry's tables (Plan.w2_pair) gets
+// both written, so that frl_sampler_run may be called on it at ANY batch size; frl_sampler_fwd, which knows the batch
+// it prepares for, writes only the region its own run reads.
 static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
-                                void* workspace, size_t workspace_bytes, void* hip_stream, int plan_flags) {
+                                void* workspace, size_t workspace_bytes, void* hip_stream, int plan_flags, bool both_regions = false,
+                                int pick = W2_PICK_BY_BATCH) {
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr) { set_error("params is NULL"); return FRL_EINVAL; }
   Plan pl;
-  plan_from_desc(*desc, pl, plan_flags);
+  plan_from_desc(*desc, pl, plan_flags, pick);
+  if (both_regions && pl.w2_pair) {
+    rc = sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, plan_flags, false, W2_PICK_32);
+    if (rc != FRL_OK) return rc;
+    return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, plan_flags, false, W2_PICK_16);
+  }
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
   for (int l = 0; l <= pl.L; ++l)
@@ -329,11 +353,12 @@ static int sampler_prepare_impl(const FrlDesc* desc, const FrlParams* params, co
 
 int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
                         void* workspace, size_t workspace_bytes, void* hip_stream) {
-  return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, PLAN_HOIST | PLAN_W2);
+  return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, PLAN_HOIST | PLAN_W2, true);
 }
 
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream) {
+  clear_kernels();
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
@@ -428,7 +453,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
 
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
                     const FrlFwdBufs* bufs, void* workspace, size_t workspace_bytes, void* hip_stream) {
-  int rc = frl_sampler_prepare(desc, params, sched, workspace, workspace_bytes, hip_stream);
+  int rc = sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, PLAN_HOIST | PLAN_W2);   // this batch's region only
   if (rc != FRL_OK) return rc;
   return frl_sampler_run(desc, params, bufs, workspace, workspace_bytes, hip_stream);
 }
@@ -563,6 +588,7 @@ static void fill_bwd_args(const FrlDesc* desc, const FrlParams* params, const Pl
 
 int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* bufs,
                           void* workspace, size_t workspace_bytes, void* hip_stream) {
+  clear_kernels();
   int rc = validate_bwd(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
@@ -622,6 +648,7 @@ int frl_sampler_fwd_train(const FrlDesc* desc, const FrlParams* params, const Fr
 
 int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlBwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream) {
+  clear_kernels();
   int rc = validate_bwd(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
@@ -744,6 +771,7 @@ size_t frl_critic_workspace_bytes(const FrlCriticDesc* desc) {
 
 int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, const FrlSelectBufs* bufs,
                       void* workspace, size_t workspace_bytes, void* hip_stream) {
+  clear_kernels();
   FrlDesc d; Plan pl; bool hoist;
   int rc = critic_plan(desc, d, pl, hoist);
   if (rc != FRL_OK) return rc;
@@ -874,6 +902,7 @@ size_t frl_net_eval_workspace_bytes(const FrlDesc* desc) {
 
 int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* workspace, size_t workspace_bytes,
                  void* hip_stream) {
+  clear_kernels();
   EvalPlan e;
   int rc = eval_plan(desc, e);
   if (rc != FRL_OK) return rc;
@@ -1025,6 +1054,7 @@ static int eval_check_params(const FrlDesc* desc, const FrlParams* params) {
 
 int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* workspace, size_t workspace_bytes,
                        void* hip_stream) {
+  clear_kernels();
   EvalBwdPlan q;
   int rc = eval_bwd_plan(desc, q);
   if (rc != FRL_OK) return rc;
@@ -1065,6 +1095,7 @@ int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEv
 
 int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEvalBwdBufs* bufs, void* workspace, size_t workspace_bytes,
                      void* hip_stream) {
+  clear_kernels();
   EvalBwdPlan q;
   int rc = eval_bwd_plan(desc, q);
   if (rc != FRL_OK) return rc;
@@ -1132,7 +1163,7 @@ int frl_add_noise(int32_t kind, int64_t B, int32_t A, const float* x0, const flo
   if (B == 0) return FRL_OK;
   if (x0 == nullptr || e == nullptr || t == nullptr || xt == nullptr) { set_error("add_noise: x0 / e / t / xt is NULL"); return FRL_EINVAL; }
   if (kind == FRL_NOISE_DDPM && (alpha_hats == nullptr || steps < 1)) { set_error("add_noise: alpha_hats (steps + 1,) required"); return FRL_EINVAL; }
-  return launch_add_noise(kind, B, A, x0, e, t, alpha_hats, p0, p1, xt, vel, (hipStream_t)hip_stream);
+  return launch_add_noise(kind, B, A, steps, x0, e, t, alpha_hats, p0, p1, xt, vel, (hipStream_t)hip_stream);
 }
 
 int frl_ddpm_onestep_update(int32_t solver, int64_t B, int32_t A, int32_t num_samples, const float* xt, const float* eps_theta,
@@ -1143,7 +1174,7 @@ int frl_ddpm_onestep_update(int32_t solver, int64_t B, int32_t A, int32_t num_sa
   if (B == 0) return FRL_OK;
   if (xt == nullptr || eps_theta == nullptr || t == nullptr || alphas == nullptr || alpha_hats == nullptr || out == nullptr) { set_error("onestep update: NULL argument"); return FRL_EINVAL; }
   if (solver == FRL_SOLVER_DDPM && noise == nullptr) { set_error("onestep update: the ddpm solver needs noise (B, num_samples, A)"); return FRL_EINVAL; }
-  return launch_onestep_update(solver, B, A, num_samples, xt, eps_theta, t, alphas, alpha_hats, clip, x_min, x_max, noise, out, (hipStream_t)hip_stream);
+  return launch_onestep_update(solver, B, A, num_samples, steps, xt, eps_theta, t, alphas, alpha_hats, clip, x_min, x_max, noise, out, (hipStream_t)hip_stream);
 }
 
 int frl_mse_loss(int64_t n, const float* pred, const float* target, float* loss, float* grad, void* workspace, size_t workspace_bytes,

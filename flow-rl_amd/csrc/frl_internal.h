@@ -65,6 +65,8 @@ struct Plan {
   int bf_l0c;           // layer-0 chunks = ceil(8 (nxk + cks) / 32)
   int bf_ns;            // chunks per step = l0c + 4 (L - 1) + 1
   size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
+  int w2_pair;          // 1: the workspace holds BOTH geometries' tables and packed images (32-chain region, then the
+                        //    16-chain region), so that it does not depend on the batch size; this Plan is one of the two
 };
 
 // Plan flags.  PLAN_HOIST off: the condition rows of Dense_0 stay in the kernel's operand (the chain VJP contracts them
@@ -73,35 +75,53 @@ struct Plan {
 // every other consumer of a Plan (VJP, single evaluation, critic) has 32-chain kernels only.
 enum { PLAN_HOIST = 1, PLAN_W2 = 2 };
 constexpr long long W2_MIN_CHAINS = 65536;   // 16 chains x 8 waves x 256 CUs x 2 tiles per wave
+enum { W2_PICK_BY_BATCH = -1, W2_PICK_32 = 0, W2_PICK_16 = 1 };
 
-inline int plan_layout(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST);
+inline int plan_layout(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST, int force_tr = 0, size_t base = 0);
 
 // The 16x16x4 geometry at two waves per SIMD (csrc/sampler_rs.hip, frl_sampler_rs_kernel_w2) runs the plain sampler
 // only: f32 MLP backbone, 256 wide, no LayerNorm, no in-kernel draws, ddpm / ddim / Euler updates, condition rows in
-// the operand (x_dim <= 16, cond_dim <= 48), and a batch large enough that every wave still gets two tiles.
-inline bool plan_two_wave(const FrlDesc& d, const Plan& p) {
+// the operand (x_dim <= 16, cond_dim <= 48) — plan_two_wave_shape, everything but the batch size — and a batch large
+// enough that every wave still gets two tiles.  A descriptor of that shape gets a workspace with BOTH geometries'
+// regions (Plan.w2_pair), so that a workspace prepared once serves frl_sampler_run at any batch size.
+inline bool plan_two_wave_shape(const FrlDesc& d, const Plan& p) {
   if (d.dtype != FRL_DTYPE_F32 || d.backbone != FRL_BACKBONE_MLP || p.H != 256 || d.layer_norm != 0 || d.rng_impl != FRL_RNG_NONE) return false;
   if (d.kind != FRL_KIND_CNF && d.solver != FRL_SOLVER_DDPM && d.solver != FRL_SOLVER_DDIM) return false;
   if (d.tile_policy != FRL_TILE_AUTO && d.tile_policy != FRL_TILE_THROUGHPUT) return false;
-  if (p.A > 16 || p.C > 48 || (d.particles >= 4 && p.C >= 32)) return false;
-  return (long long)d.n_states * d.particles >= W2_MIN_CHAINS;
+  if (d.cond_embed) return false;
+  return !(p.A > 16 || p.C > 48 || (d.particles >= 4 && p.C >= 32));
+}
+inline bool plan_two_wave(const FrlDesc& d, const Plan& p) {
+  return plan_two_wave_shape(d, p) && (long long)d.n_states * d.particles >= W2_MIN_CHAINS;
 }
 
-inline int plan_from_desc(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST) {
+// pick (PLAN_W2 only): which of the two regions of a paired workspace the returned Plan describes
+inline int plan_from_desc(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST, int pick = W2_PICK_BY_BATCH) {
   p.A = d.x_dim; p.C = d.cond_dim; p.T = d.steps;
   p.L = (d.backbone != FRL_BACKBONE_MLP) ? 1 : d.n_hidden;   // residual classes: Dense_0 -> [blocks] -> Dense_1 around ONE 256-wide trunk
   p.D = (d.time_embed == FRL_TEMB_NONE) ? 0 : d.time_dim;
   p.Dp = (d.time_embed == FRL_TEMB_NONE) ? 1 : d.time_dim;
   p.AO = p.A; p.x_row0 = 0; p.c_row0 = p.A + p.Dp;
   p.H = d.hidden[0];
-  return plan_layout(d, p, flags);
+  plan_layout(d, p, flags);
+  if ((flags & PLAN_W2) != 0 && plan_two_wave_shape(d, p)) {
+    Plan q = p;
+    plan_layout(d, q, flags, 16, p.total_floats);     // the 16-chain region sits behind the 32-chain one
+    const bool take16 = pick == W2_PICK_16 || (pick == W2_PICK_BY_BATCH && plan_two_wave(d, p));
+    const size_t total = q.total_floats;
+    if (take16) p = q;
+    p.total_floats = total;
+    p.w2_pair = 1;
+  }
+  return 0;
 }
 
 // Second half of the plan: geometry and workspace layout from the (possibly overridden) dims above.
-inline int plan_layout(const FrlDesc& d, Plan& p, int flags) {
+inline int plan_layout(const FrlDesc& d, Plan& p, int flags, int force_tr, size_t base) {
   const bool allow_hoist = (flags & PLAN_HOIST) != 0;
   p.TR = (p.H <= 256) ? 32 : 16;
-  if ((flags & PLAN_W2) != 0 && plan_two_wave(d, p)) p.TR = 16;
+  if (force_tr != 0) p.TR = force_tr;
+  p.w2_pair = 0;
   p.KS = (p.TR == 32) ? 2 : 4;
   p.NR = (p.TR == 32) ? 16 : 4;
   p.XR = 4 * p.KS * ((p.A + 4 * p.KS - 1) / (4 * p.KS));
@@ -121,7 +141,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p, int flags) {
            : (d.solver == FRL_SOLVER_DPMPP2M) ? MODE_CDDPM_DPMPP2M : MODE_CDDPM_DDPM;
   else p.mode = MODE_CNF_EULER;
   p.NE = (p.mode == MODE_CDDPM_DPM2) ? 2 * p.T : p.T;
-  size_t o = 0;
+  size_t o = base;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };  // 256-B aligned pieces
   p.off_coef = take((size_t)p.NE * COEF_STRIDE);
   p.off_tb = take((size_t)p.NE * p.H);
@@ -131,8 +151,6 @@ inline int plan_layout(const FrlDesc& d, Plan& p, int flags) {
   p.off_wlp = take((size_t)p.H * LAST_PAD);   // [H][32] image (LDS-slab kernel)
   p.off_wlq = take((size_t)p.H * 64);         // per-lane packed image: H/TR * NR/4 loads x 64 lanes x 4 floats
   p.off_blp = take(LAST_PAD);
-  p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
-  p.off_zs = take(p.hoist ? (size_t)d.n_states * p.H : 0);                     // hoisted cond slice of Dense_0, one row per state
   p.off_keys = take(d.rng_impl != FRL_RNG_NONE ? (size_t)p.NE * 2 : 0);        // per-iteration threefry keys (uint32 pairs)
   p.off_ln = take((d.layer_norm && d.backbone == FRL_BACKBONE_MLP) ? (size_t)p.L * 2 * p.H : 0);                    // LayerNorm scale | bias rows, [L][2][H]
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
@@ -141,6 +159,11 @@ inline int plan_layout(const FrlDesc& d, Plan& p, int flags) {
   p.bf_l0c = (8 * (p.bf_nxk + p.bf_cks) + 31) / 32;
   p.bf_ns = p.bf_l0c + 4 * (p.L - 1) + 1;
   p.off_bf16 = take(p.bf16 ? (size_t)p.bf_ns * (BF_CHUNK_BYTES / 4) : 0);
+  // Everything above is written by frl_sampler_prepare and sits at offsets that do not depend on n_states; the per-state
+  // rows below are written by frl_sampler_run itself.  So a workspace prepared once serves runs at any batch size it is
+  // large enough for (frl_workspace_bytes of the run's descriptor).
+  p.off_cfeat = take(d.cond_embed ? (size_t)d.n_states * COND_EMBED_DIM : 0);   // cond_embedding output, one row per state
+  p.off_zs = take(p.hoist ? (size_t)d.n_states * p.H : 0);                     // hoisted cond slice of Dense_0, one row per state
   p.total_floats = o;
   return 0;
 }
@@ -382,6 +405,9 @@ template <> int launch_bwd_sweep_phase<1>(const FrlDesc& d, const BArgs& b, hipS
 template <> int launch_bwd_sweep_phase<2>(const FrlDesc& d, const BArgs& b, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+// Names of the compute kernels launched by the current C-ABI call on this thread (frl_last_kernels): every launcher appends
+// the instantiation it actually enqueued, so a report of "which kernel ran" can never drift from the dispatch rules.
+void note_kernel(const char* fmt, ...);
 
 // launchers implemented in the .hip files
 int launch_prepare(const PArgs& a, hipStream_t stream);
@@ -431,9 +457,9 @@ int launch_random_uniform(const uint32_t* key, int impl, long long n, float lo, 
 int launch_random_randint(const uint32_t* key, int impl, long long n, int32_t minval, int32_t maxval, int32_t* out, hipStream_t stream);
 // csrc/net_eval.hip: per-sample-time evaluation rows and the forward-process pieces
 int launch_time_rows(const FrlDesc& d, const FrlParams& p, const float* t, const float* cond, int C, float* u, long long B, hipStream_t stream);
-int launch_add_noise(int kind, long long B, int A, const float* x0, const float* e, const void* t, const float* alpha_hats, float p0, float p1,
+int launch_add_noise(int kind, long long B, int A, int steps, const float* x0, const float* e, const void* t, const float* alpha_hats, float p0, float p1,
                      float* xt, float* vel, hipStream_t stream);
-int launch_onestep_update(int solver, long long B, int A, int N, const float* xt, const float* eps, const int32_t* t, const float* alphas,
+int launch_onestep_update(int solver, long long B, int A, int N, int steps, const float* xt, const float* eps, const int32_t* t, const float* alphas,
                           const float* alpha_hats, int clip, float x_min, float x_max, const float* noise, float* out, hipStream_t stream);
 int launch_mse(long long n, const float* pred, const float* target, float* loss, float* grad, void* ws, hipStream_t stream);
 int launch_selftest_mfma32(const float* A, const float* B, float* D, int K, hipStream_t stream);

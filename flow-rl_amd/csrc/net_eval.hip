@@ -249,14 +249,21 @@ int launch_time_bwd_samples(const TimeBwdSampleArgs& a, hipStream_t stream) {
 }
 
 // ---- forward process -----------------------------------------------------------------------------------------------
+// table[t] as jnp indexes it (ddpm.py:169,257-259 index the (steps + 1,) tables with the caller's per-sample t): a negative
+// index wraps once, numpy style, and what is still out of range is clamped — never an out-of-bounds read
+__device__ __forceinline__ int jnp_index(int t, int n) {
+  if (t < 0) t += n;
+  return t < 0 ? 0 : (t >= n ? n - 1 : t);
+}
+
 __global__ void __launch_bounds__(256)
-frl_add_noise_kernel(int kind, long long B, int A, const float* __restrict__ x0, const float* __restrict__ e, const void* __restrict__ tv,
+frl_add_noise_kernel(int kind, long long B, int A, int steps, const float* __restrict__ x0, const float* __restrict__ e, const void* __restrict__ tv,
                      const float* __restrict__ alpha_hats, float p0, float p1, float* __restrict__ xt, float* __restrict__ vel) {
   const long long n = B * A;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / A;
     if (kind == FRL_NOISE_DDPM) {
-      const float ah = alpha_hats[((const int32_t*)tv)[b]];
+      const float ah = alpha_hats[jnp_index(((const int32_t*)tv)[b], steps + 1)];
       xt[i] = sqrtf(ah) * x0[i] + sqrtf(1.0f - ah) * e[i];                         // ddpm.py:170
     } else if (kind == FRL_NOISE_FLOW) {
       const float t = ((const float*)tv)[b];
@@ -281,11 +288,11 @@ frl_add_noise_kernel(int kind, long long B, int A, const float* __restrict__ x0,
   }
 }
 
-int launch_add_noise(int kind, long long B, int A, const float* x0, const float* e, const void* t, const float* alpha_hats, float p0,
+int launch_add_noise(int kind, long long B, int A, int steps, const float* x0, const float* e, const void* t, const float* alpha_hats, float p0,
                      float p1, float* xt, float* vel, hipStream_t stream) {
   if (B <= 0) return FRL_OK;
   const long long n = B * A, want = (n + 255) / 256, cap = 16ll * device_cus();
-  hipLaunchKernelGGL(frl_add_noise_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, kind, B, A, x0, e, t, alpha_hats, p0, p1, xt, vel);
+  hipLaunchKernelGGL(frl_add_noise_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, kind, B, A, steps, x0, e, t, alpha_hats, p0, p1, xt, vel);
   hipError_t er = hipGetLastError();
   if (er != hipSuccess) { set_error("add_noise launch: %s", hipGetErrorString(er)); return FRL_EHIP; }
   return FRL_OK;
@@ -294,7 +301,7 @@ int launch_add_noise(int kind, long long B, int A, const float* x0, const float*
 // DDPM.onestep_sample's update for per-sample t (ddpm.py:256-274): xt_1 from (xt, eps_theta, t), repeated num_samples times,
 // ddpm: + (t > 1) sqrt(1 - alphas[t]) noise (note: sqrt(beta_t), not the posterior variance the sampler uses); ddim: clip.
 __global__ void __launch_bounds__(256)
-frl_onestep_update_kernel(int solver, long long B, int A, int N, const float* __restrict__ xt, const float* __restrict__ eps,
+frl_onestep_update_kernel(int solver, long long B, int A, int N, int steps, const float* __restrict__ xt, const float* __restrict__ eps,
                           const int32_t* __restrict__ tt, const float* __restrict__ alphas, const float* __restrict__ alpha_hats, int clip,
                           float x_min, float x_max, const float* __restrict__ noise, float* __restrict__ out) {
   const long long n = B * N * A;
@@ -303,7 +310,7 @@ frl_onestep_update_kernel(int solver, long long B, int A, int N, const float* __
     const long long b = i / ((long long)N * A);
     const int t = tt[b];
     const float x = xt[b * A + ai], e = eps[b * A + ai];
-    const float ah = alpha_hats[t], ah1 = alpha_hats[t - 1], al = alphas[t];
+    const float ah = alpha_hats[jnp_index(t, steps + 1)], ah1 = alpha_hats[jnp_index(t - 1, steps + 1)], al = alphas[jnp_index(t, steps + 1)];
     float r;
     if (solver == FRL_SOLVER_DDPM) {
       float x0h = 1.0f / sqrtf(ah) * (x - sqrtf(1.0f - ah) * e);
@@ -319,11 +326,11 @@ frl_onestep_update_kernel(int solver, long long B, int A, int N, const float* __
   }
 }
 
-int launch_onestep_update(int solver, long long B, int A, int N, const float* xt, const float* eps, const int32_t* t, const float* alphas,
+int launch_onestep_update(int solver, long long B, int A, int N, int steps, const float* xt, const float* eps, const int32_t* t, const float* alphas,
                           const float* alpha_hats, int clip, float x_min, float x_max, const float* noise, float* out, hipStream_t stream) {
   if (B <= 0) return FRL_OK;
   const long long n = B * N * A, want = (n + 255) / 256, cap = 16ll * device_cus();
-  hipLaunchKernelGGL(frl_onestep_update_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, solver, B, A, N, xt, eps, t,
+  hipLaunchKernelGGL(frl_onestep_update_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, solver, B, A, N, steps, xt, eps, t,
                      alphas, alpha_hats, clip, x_min, x_max, noise, out);
   hipError_t er = hipGetLastError();
   if (er != hipSuccess) { set_error("onestep update launch: %s", hipGetErrorString(er)); return FRL_EHIP; }

@@ -372,6 +372,7 @@ static int launch_inst_bf(const KArgs& a, int grid, size_t lds, hipStream_t stre
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_sampler_bf16_kernel<act %d, NRX %d, CKS %d> [grid %d]", ACT, NRX, CKS, grid);
   return FRL_OK;
 }
 

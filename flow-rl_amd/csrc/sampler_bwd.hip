@@ -888,6 +888,7 @@ static int launch_sweep_inst(const BArgs& b, int grid, int block, size_t lds, hi
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bwd sweep launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_bwd_sweep_kernel<act %d, NRX %d, CKMAX %d, PHASE %d> [grid %d x %d waves]", ACT, NRX, CKMAX, FRL_BWD_PHASE, grid, block / 64);
   return FRL_OK;
 }
 
@@ -943,6 +944,7 @@ int launch_sampler_bwd(const FrlDesc& d, const BArgs& b, int phase, hipStream_t 
   hipLaunchKernelGGL(frl_bwd_dw_kernel, dim3((int)g2), dim3(512), lds2, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bwd dW launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_bwd_dw_kernel [grid %d] + frl_bwd_reduce_kernel", (int)g2);
   return launch_bwd_reduce(b, stream);
 }
 #endif

@@ -694,6 +694,7 @@ static int launch_dw16_inst(const BArgs& b, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(kern, dim3(g2), dim3(512), lds2, stream, b);
+  note_kernel("frl_bwd_dw_bf16_kernel<act %d> [grid %d] + frl_bwd_reduce_kernel", ACT, g2);
   return FRL_OK;
 }
 
@@ -716,6 +717,7 @@ static int launch_sweep16(const BArgs& b, int grid, size_t lds, hipStream_t stre
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 bwd sweep launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_bwd_sweep_bf16_kernel<act %d, PHASE %d> [grid %d]", ACT, FRL_BWD16_PHASE, grid);
   return FRL_OK;
 }
 

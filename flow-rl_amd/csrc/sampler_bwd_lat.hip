@@ -337,6 +337,7 @@ int launch_inst(const BArgs& b, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, b);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("latency backward sweep launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_bwd_sweep_lat_kernel<TR %d, NRX %d%s> [grid %d]", TR, NRX, DCOND ? ", DCOND" : "", grid);
   return FRL_OK;
 }
 

@@ -440,6 +440,7 @@ static int launch_lat_inst(KArgs& a, int ncu, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("latency sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_sampler_lat_kernel<TR %d, H %d, act %d, NRX %d, CKMAX %d%s> [grid %d]", TR, H, ACT, NRX, CKMAX, STASH ? ", STASH" : "", grid);
   return FRL_OK;
 }
 

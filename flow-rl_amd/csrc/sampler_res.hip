@@ -389,6 +389,7 @@ static int launch_res_inst(const KArgs& a, const ResArgs& ra, hipStream_t stream
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, stream, a, ra);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("residual sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_sampler_res_kernel<act %d, NRX %d> [grid %d x %d waves]", ACT, NRX, grid, nw);
   return FRL_OK;
 }
 

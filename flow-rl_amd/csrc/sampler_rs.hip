@@ -405,7 +405,7 @@ static int device_cus_rs() {
 }
 
 // `configured`: the launching instantiation's per-device record of the dynamic-LDS size its kernel was last set up for
-static int launch_kern(const void* kern, size_t* configured, int TR, int H, int max_waves, const KArgs& a, hipStream_t stream) {
+static int launch_kern(const void* kern, const char* tag, size_t* configured, int TR, int H, int max_waves, const KArgs& a, hipStream_t stream) {
   const int ncu = device_cus_rs();
   const long long n_wt = (a.B + TR - 1) / TR;
   long long per_cu = (n_wt + ncu - 1) / ncu;
@@ -428,13 +428,16 @@ static int launch_kern(const void* kern, size_t* configured, int TR, int H, int 
   hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(64 * nw), argv, lds, stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_error("sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("%s [grid %d x %d waves]", tag, grid, nw);
   return FRL_OK;
 }
 
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
 static int launch_inst_v(const KArgs& a, hipStream_t stream) {
   static thread_local size_t configured[16] = {0};
-  return launch_kern((const void*)frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX, EXT>, configured, TR, H, MAX_WAVES, a, stream);
+  char tag[96];
+  snprintf(tag, sizeof(tag), "frl_sampler_rs_kernel<TR %d, H %d, act %d, NRX %d, CKMAX %d, EXT %d>", TR, H, ACT, NRX, CKMAX, EXT);
+  return launch_kern((const void*)frl_sampler_rs_kernel<TR, H, ACT, NRX, CKMAX, EXT>, tag, configured, TR, H, MAX_WAVES, a, stream);
 }
 
 // the two-wave build: up to eight waves per workgroup (two per SIMD), plain sampler only (plan_two_wave guarantees it)
@@ -445,7 +448,9 @@ static int launch_w2(const KArgs& a, hipStream_t stream) {
     if (a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr || a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.AR > 4 || a.CK > 12) {
       set_error("two-wave build asked for a path it does not carry (plan / launch mismatch)"); return FRL_EINVAL; }
     static thread_local size_t configured[16] = {0};
-    return launch_kern((const void*)frl_sampler_rs_kernel_w2<ACT>, configured, 16, 256, 2 * MAX_WAVES, a, stream);
+    char tag[64];
+    snprintf(tag, sizeof(tag), "frl_sampler_rs_kernel_w2<act %d>", ACT);
+    return launch_kern((const void*)frl_sampler_rs_kernel_w2<ACT>, tag, configured, 16, 256, 2 * MAX_WAVES, a, stream);
   }
 }
 

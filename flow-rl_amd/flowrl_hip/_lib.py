@@ -113,6 +113,7 @@ LIB_PATH = Path(os.environ.get("FLOWRL_HIP_LIB", Path(__file__).resolve().parent
 EXPORTS = {
     "frl_abi_version": (C.c_int, []),
     "frl_last_error": (C.c_char_p, []),
+    "frl_last_kernels": (C.c_char_p, []),
     "frl_validate": (C.c_int, [C.POINTER(FrlDesc)]),
     "frl_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc)]),
     "frl_algorithmic_flops": (C.c_double, [C.POINTER(FrlDesc), C.POINTER(C.c_double)]),

@@ -421,6 +421,36 @@ def run_sampler_train(network, params: Dict, *, kind: int, solver: int, steps: i
     return x0.reshape(*lead, A), hist, ctx
 
 
+class GradTree(dict):
+    """A gradient tree (Flax layout) whose leaves are views of ``flat``, one f32 buffer (leaves start at multiples of 64
+    floats; the gaps are zero)."""
+    flat: Optional[torch.Tensor] = None
+
+
+def alloc_grad_tree(params: Dict, paths, device: torch.device) -> "GradTree":
+    """Contiguous f32 leaves with the shapes of ``params`` at ``paths``, carved out of one zero-filled flat buffer."""
+    shapes = []
+    for path in paths:
+        node = params
+        for k in path:
+            node = node[k]
+        shapes.append(tuple(node.shape))
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    offs, o = [], 0
+    for nel in sizes:
+        offs.append(o)
+        o += (nel + 63) & ~63
+    flat = torch.zeros(max(o, 1), dtype=torch.float32, device=device)
+    tree = GradTree()
+    for path, sh, nel, off in zip(paths, shapes, sizes, offs):
+        node = tree
+        for k in path[:-1]:
+            node = node.setdefault(k, {})
+        node[path[-1]] = flat[off:off + nel].view(sh)
+    tree.flat = flat
+    return tree
+
+
 # ---- chain VJP -----------------------------------------------------------------------------------------------
 def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int, xt_hist: torch.Tensor,
                     condition: Optional[torch.Tensor], g_x0: torch.Tensor, sched: Dict[str, torch.Tensor],
@@ -454,7 +484,17 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
     pname = network.predictor_name
     n = len(network.predictor.hidden_dims)
     H = int(network.predictor.hidden_dims[0])
-    grads: Dict = {pname: {}}
+    te = network.time_embedding
+    # Every gradient leaf is a view of ONE flat f32 buffer (GradTree.flat): the multi-GPU all-reduce of the gradients is
+    # then a single collective on that buffer, with no concatenation or copy-back kernels (parallel.all_reduce_grads).
+    paths = [(pname, f"Dense_{i}", w) for i in range(n + 1) for w in ("kernel", "bias")]
+    if te is not None:      # the library finishes the time branch: MLP_0 leaves (+ the Fourier kernel)
+        paths += [("MLP_0", f"Dense_{i}", w) for i in range(2) for w in ("kernel", "bias")]
+        if isinstance(te, LearnableFourierEmbedding):
+            paths.append(("time_embedding", "kernel"))
+    if network.cond_embedding is not None:      # DACER differentiates the embedding too (dacer.py:141-162)
+        paths += [("cond_embedding", f"Dense_{i}", w) for i in range(2) for w in ("kernel", "bias")]
+    grads = alloc_grad_tree(params, paths, device)
     bufs = _lib.FrlBwdBufs()
     bufs.xt_hist, bufs.g_x0 = xt_hist.data_ptr(), g_in.data_ptr()
     if cond2d is not None:
@@ -463,35 +503,20 @@ def run_sampler_vjp(network, params: Dict, *, kind: int, solver: int, steps: int
     if g_xT is not None:
         bufs.g_xT = g_xT.data_ptr()
     for i in range(n + 1):
-        k = params[pname][f"Dense_{i}"]
-        gk = torch.empty_like(k["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
-        gb = torch.empty_like(k["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
-        grads[pname][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
-        bufs.grad_kernel[i], bufs.grad_bias[i] = gk.data_ptr(), gb.data_ptr()
+        g = grads[pname][f"Dense_{i}"]
+        bufs.grad_kernel[i], bufs.grad_bias[i] = g["kernel"].data_ptr(), g["bias"].data_ptr()
     grad_tb = torch.empty((steps, H), dtype=torch.float32, device=device)
     bufs.grad_tb = grad_tb.data_ptr()
-    te = network.time_embedding
-    if te is not None:      # the library finishes the time branch: MLP_0 leaves (+ the Fourier kernel)
-        grads["MLP_0"] = {}
+    if te is not None:
         for i in range(2):
-            k = params["MLP_0"][f"Dense_{i}"]
-            gk = torch.empty_like(k["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
-            gb = torch.empty_like(k["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
-            grads["MLP_0"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
-            bufs.grad_tmlp_kernel[i], bufs.grad_tmlp_bias[i] = gk.data_ptr(), gb.data_ptr()
+            g = grads["MLP_0"][f"Dense_{i}"]
+            bufs.grad_tmlp_kernel[i], bufs.grad_tmlp_bias[i] = g["kernel"].data_ptr(), g["bias"].data_ptr()
         if isinstance(te, LearnableFourierEmbedding):
-            gw = torch.empty_like(params["time_embedding"]["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
-            grads["time_embedding"] = {"kernel": gw}
-            bufs.grad_time_kernel = gw.data_ptr()
-
-    if network.cond_embedding is not None:      # DACER differentiates the embedding too (dacer.py:141-162)
-        grads["cond_embedding"] = {}
+            bufs.grad_time_kernel = grads["time_embedding"]["kernel"].data_ptr()
+    if network.cond_embedding is not None:
         for i in range(2):
-            k = params["cond_embedding"][f"Dense_{i}"]
-            gk = torch.empty_like(k["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
-            gb = torch.empty_like(k["bias"], dtype=torch.float32, memory_format=torch.contiguous_format)
-            grads["cond_embedding"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
-            bufs.grad_cond_kernel[i], bufs.grad_cond_bias[i] = gk.data_ptr(), gb.data_ptr()
+            g = grads["cond_embedding"][f"Dense_{i}"]
+            bufs.grad_cond_kernel[i], bufs.grad_cond_bias[i] = g["kernel"].data_ptr(), g["bias"].data_ptr()
 
     need = lib.frl_bwd_workspace_bytes(C.byref(desc))
     if need == 0:   # invalid / unsupported descriptor: let the entry point say why

@@ -70,7 +70,10 @@ class _SampleFn(torch.autograd.Function):
     def forward(ctx, model, rng, condition, kw, paths, xT, *leaves):
         params = tree_build(paths, leaves)
         rng_out, x0, (xh, eh, vctx) = model.sample(rng, xT, condition, True, params=params, keep_for_vjp=True, **kw)
-        ctx.model, ctx.condition, ctx.kw, ctx.paths, ctx.params, ctx.vctx = model, condition, kw, paths, params, vctx
+        ctx.model, ctx.condition, ctx.kw, ctx.paths, ctx.vctx = model, condition, kw, paths, vctx
+        # saved through autograd so that an in-place change of xT / a parameter leaf between forward and backward is caught
+        # by the version counters (the stash was computed from the old values)
+        ctx.save_for_backward(xT, *leaves)
         ctx.mark_non_differentiable(*[t for t in (xh, eh, rng_out) if torch.is_tensor(t)])
         return x0, xh, eh, rng_out      # rng_out: the advanced threefry key (a tensor), or the caller's generator / None as it came
 
@@ -81,8 +84,10 @@ class _SampleFn(torch.autograd.Function):
         want_gx = ctx.needs_input_grad[5]
         bkw = {k: kw[k] for k in ("solver", "steps", "t_schedule_n", "particles", "compute_dtype") if k in kw}
         bkw["want_gx0" if isinstance(model, ContinuousNormalizingFlow) else "want_gxT"] = want_gx
-        grads, g_x = model.sample_vjp(None, g_x0.contiguous(), ctx.condition, params=ctx.params, ctx=ctx.vctx, **bkw)
-        ctx.vctx = None      # the stash (the context's workspace) goes back to the allocator now
+        params = tree_build(ctx.paths, ctx.saved_tensors[1:])
+        # the stash (the context's workspace) is only read by the backward and lives as long as the autograd node: a second
+        # backward through the same graph (retain_graph=True, two losses sharing one sample) runs from it again
+        grads, g_x = model.sample_vjp(None, g_x0.contiguous(), ctx.condition, params=params, ctx=ctx.vctx, **bkw)
         g_leaves = [(_lookup(grads, p) if need else None) for p, need in zip(ctx.paths, ctx.needs_input_grad[6:])]
         return (None, None, None, None, None, g_x, *g_leaves)
 
@@ -110,13 +115,14 @@ class _ApplyFn(torch.autograd.Function):
         params = tree_build(paths, leaves)
         out, ectx = model(x, t, condition, True, params, particles=particles, keep_for_vjp=True)
         ctx.model, ctx.paths, ctx.ectx = model, paths, ectx
+        ctx.save_for_backward(x, *leaves)      # version-counter checks, as in _SampleFn
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out):
+        _ = ctx.saved_tensors                   # raises if x / a leaf was modified in place since the forward
         grads, g_x = ctx.model.eval_vjp(ctx.ectx, g_out.contiguous(), want_gx=ctx.needs_input_grad[5])
-        ctx.ectx = None
         g_leaves = [(_lookup(grads, p) if need else None) for p, need in zip(ctx.paths, ctx.needs_input_grad[6:])]
         return (None, None, None, None, None, g_x, *g_leaves)
 

@@ -52,15 +52,23 @@ class ContinuousDDPM:
                    x_max=x_max, solver=solver, t_schedule_n=t_schedule_n, t_diffusion=t_diffusion, noise_schedule_func=fn)
 
     def replace(self, **kw) -> "ContinuousDDPM":
-        return replace(self, **kw)
+        """dataclasses.replace builds a NEW instance; the device-table cache travels with it (the entries are keyed by the
+        schedule function and t_diffusion too, so a replaced schedule simply misses): `model.apply_gradient` replaces the
+        model every optimizer step, and rebuilding the tables there costs four synchronous host-to-device copies per step."""
+        new = replace(self, **kw)
+        cache = self.__dict__.get("_tables")
+        if cache is not None:
+            new.__dict__["_tables"] = cache
+        return new
 
     def _device_tables(self, steps: int, t_schedule_n: float, midpoints: bool, dev) -> Dict[str, torch.Tensor]:
         """The per-call tables of continuous_ddpm.py:134-138 (and the dpm2 midpoints, :181-184), built once per
         (steps, t_schedule_n, device) and kept on the GPU: the reference rebuilds them inside every jitted call, where
         XLA constant-folds them."""
         cache = self.__dict__.setdefault("_tables", {})
-        key = (steps, float(t_schedule_n), bool(midpoints), str(dev))
-        sched = cache.get(key)
+        key = (steps, float(t_schedule_n), bool(midpoints), str(dev), id(self.noise_schedule_func), tuple(float(v) for v in self.t_diffusion))
+        ent = cache.get(key)
+        sched = ent[1] if ent is not None and ent[0] is self.noise_schedule_func else None    # the entry keeps its function alive: ids are not recycled
         if sched is None:
             to = lambda v: torch.from_numpy(v).to(dev)
             ts, ah, al, be = schedules.continuous_tables(steps, self.noise_schedule_func, self.t_diffusion, t_schedule_n)
@@ -68,7 +76,7 @@ class ContinuousDDPM:
             if midpoints:
                 mid, mal, msg = schedules.continuous_midpoints(ts, self.noise_schedule_func)
                 sched.update(mid_ts=to(mid), mid_alphas=to(mal), mid_sigmas=to(msg))
-            cache[key] = sched
+            cache[key] = (self.noise_schedule_func, sched)
         return sched
 
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,

@@ -82,6 +82,11 @@ def all_reduce_grads(grads: dict, group=None) -> dict:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return grads
+    flat = getattr(grads, "flat", None)
+    if flat is not None:
+        # the library's VJP wrote its leaves into one flat buffer (_sampler.GradTree): the collective runs on it in place
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return grads
     items = list(_leaves(grads))
     flat = torch.cat([v.reshape(-1) for _, v in items])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

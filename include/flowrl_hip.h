@@ -202,9 +202,12 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
                         void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Stage 2: (cond_embedding kernel, once per state, when desc.cond_embed) + the persistent fused T-step kernel.  Needs a workspace filled by frl_sampler_prepare
- * for the same desc/params on the same stream (or an earlier, completed one).  "Same desc" includes n_states and
- * particles: the kernel geometry (and with it the packed edge-layer images prepare writes) is chosen from the batch
- * size, e.g. 16-chain tiles at two waves per SIMD from 65536 chains of a plain 256-wide sampler. */
+ * for the same desc/params on the same stream (or an earlier, completed one).  "Same desc" EXCEPT n_states: a prepared
+ * workspace serves runs at any n_states whose frl_workspace_bytes fits it.  (The kernel geometry is chosen from the batch
+ * size — 16-chain tiles at two waves per SIMD from 65536 chains of a plain 256-wide sampler — so for descriptors of that
+ * shape the workspace holds, and frl_sampler_prepare writes, the tables and packed edge-layer images of BOTH geometries;
+ * everything prepare writes sits at offsets that do not depend on n_states.)  particles, like every other field, must
+ * match the prepared descriptor. */
 int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
                     void* workspace, size_t workspace_bytes, void* hip_stream);
 
@@ -337,6 +340,11 @@ double frl_hoisted_flops(const FrlDesc* desc);
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* frl_last_error(void);
+
+/* Diagnostics (no reference counterpart): the compute kernels the LAST sampler / VJP / evaluation / critic entry point called
+ * on this thread actually enqueued, as "name<instantiation> [grid] + ..." (thread-local; "" before any call).  Written by
+ * the launchers themselves, so a benchmark that reports which build ran cannot drift from the dispatch rules. */
+const char* frl_last_kernels(void);
 
 /* ABI version this library was built with. */
 /* jax.random pieces for the callers either side of the sampler (dql.py:142-146 draws xT with its own split before

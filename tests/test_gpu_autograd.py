@@ -227,3 +227,29 @@ def test_no_grad_calls_take_the_plain_paths():
     assert rng is None and x0.grad_fn is None and out.grad_fn is None
     assert torch.equal(x0, x0_ref) and torch.equal(xh, xh_ref) and torch.equal(eh, eh_ref)
     assert out.shape == (case.B, case.A) and torch.isfinite(out).all()
+
+
+def test_second_backward_and_inplace_change_detection():
+    """a second backward through the same graph (retain_graph=True) must run from the kept stash and give the
+    same bits; an in-place change of a parameter leaf between forward and backward must be caught by the version counter."""
+    import torch
+    import flowrl_hip.autograd as fa
+    case = H.Case("ag-twice", "ddpm", A=3, S=11, T=5, B=128, seed=35)
+    params, xT, cond, noise = H.make_inputs(case)
+    model = H.product_model(case, params)
+    x, c, nz = (torch.from_numpy(v).cuda() for v in (xT, cond, noise))
+    leaves = [leaf.detach().requires_grad_(True) for _, leaf in fa.tree_leaves(model.params)]
+    p = fa.tree_build([path for path, _ in fa.tree_leaves(model.params)], leaves)
+    _, x0, _ = fa.sample(model, None, x, c, params=p, solver="ddpm", noise=nz)
+    loss = (x0 ** 2).sum()
+    g1 = torch.autograd.grad(loss, leaves, retain_graph=True, allow_unused=True)
+    g2 = torch.autograd.grad(loss, leaves, retain_graph=True, allow_unused=True)
+    torch.cuda.synchronize()
+    for a, b in zip(g1, g2):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    with torch.no_grad():
+        leaves[0].add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        torch.autograd.grad(loss, leaves, allow_unused=True)

@@ -95,3 +95,65 @@ def test_update_through_dot_data_is_seen_by_default():
     again = H.product_run(case, model, xT, cond, noise, cache_prepare=True)
     ref2 = H.oracle_run(case, params, xT, cond, noise, dtype=np.float64)
     assert H.rel_err(again[0], ref2[0]) <= 5e-5 and not np.array_equal(hot[0], again[0])
+
+
+@pytest.mark.parametrize("cond_embed", [False, True], ids=["plain-w2-shape", "cond-embed-hoist"])
+def test_prepared_workspace_serves_any_batch_size(cond_embed):
+    """frl_sampler_run used to need the n_states frl_sampler_prepare saw (the packed edge-layer images
+    switch geometry at 65 536 chains of a plain 256-wide sampler; per-state rows sat in front of prepared regions).  Now
+    everything prepare writes is independent of n_states: ONE prepare at a small batch, then runs at batches on both
+    sides of the threshold over the same workspace, each bit-identical to its own frl_sampler_fwd."""
+    import ctypes as C
+    import torch
+    from flowrl_hip import _lib, _sampler
+    lib = _lib.load()
+    if cond_embed:
+        case = H.Case("dacer-like", "cddpm", A=6, S=40, T=4, B=70016, particles=8, temb="learnable_fourier", schedule="cosine", cond_embed=True)
+    else:
+        case = H.Case("dql", "ddpm", A=3, S=11, T=3, B=70016)
+    params, xT, cond, noise = H.make_inputs(case)
+    model = H.product_model(case, params)
+    dev = torch.device("cuda")
+    x, c, nz = (torch.from_numpy(v).to(dev) for v in (xT, cond, noise))
+    keep = []
+    kind = _lib.FRL_KIND_DDPM if case.kind == "ddpm" else _lib.FRL_KIND_CDDPM
+
+    def desc_for(n_states):
+        return _sampler.build_desc(model.network, kind=kind, solver=_lib.FRL_SOLVER_DDPM, steps=case.T, n_states=n_states,
+                                   particles=case.particles, x_dim=case.A, cond_dim=case.S, clip_sampler=True, x_min=-1.0, x_max=1.0,
+                                   want_history=False)
+
+    fp = _sampler.build_params(model.network, model.params, dev, keep)
+    fs = _lib.FrlSchedule()
+    if case.kind == "ddpm":
+        tabs = dict(betas=model.betas, alphas=model.alphas, alpha_hats=model.alpha_hats, postvars=model.postvars)
+    else:
+        from flowrl_hip import schedules as sch
+        ts, ah, al, be = sch.continuous_tables(case.T, model.noise_schedule_func, model.t_diffusion, model.t_schedule_n)
+        tabs = {k: torch.from_numpy(v).to(dev) for k, v in dict(ts=ts, alpha_hats=ah, alphas=al, betas=be).items()}
+    for k, v in tabs.items():
+        keep.append(v)
+        setattr(fs, k, v.data_ptr())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n_big = case.B // case.particles
+    sizes = [n_big, 1000 // case.particles, 37]
+    need = max(lib.frl_workspace_bytes(C.byref(desc_for(n))) for n in sizes)
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    d_small = desc_for(sizes[1])
+    _lib.check(lib.frl_sampler_prepare(C.byref(d_small), C.byref(fp), C.byref(fs), ws.data_ptr(), need, stream))     # ONCE, at the small batch
+    for n in sizes:
+        B = n * case.particles
+        d = desc_for(n)
+        xb, cb, nb = x[:B].contiguous(), c[:n].contiguous(), nz[:, :B].contiguous()
+        got, ref = torch.empty_like(xb), torch.empty_like(xb)
+        bufs = _lib.FrlFwdBufs()
+        bufs.xT, bufs.cond, bufs.noise, bufs.x0 = xb.data_ptr(), cb.data_ptr(), nb.data_ptr(), got.data_ptr()
+        _lib.check(lib.frl_sampler_run(C.byref(d), C.byref(fp), C.byref(bufs), ws.data_ptr(), need, stream))
+        ws2 = torch.zeros(need, dtype=torch.uint8, device=dev)
+        bufs.x0 = ref.data_ptr()
+        _lib.check(lib.frl_sampler_fwd(C.byref(d), C.byref(fp), C.byref(fs), C.byref(bufs), ws2.data_ptr(), need, stream))
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, ref), f"run at n_states = {n} over a workspace prepared at n_states = {sizes[1]} differs from its own frl_sampler_fwd"
+    o = H.oracle_run(H.Case(**{**case.__dict__, "B": 37 * case.particles}), params, xT[:37 * case.particles], cond[:37], noise[:, :37 * case.particles], dtype=np.float64)
+    assert H.rel_err(got.cpu().numpy(), o[0]) <= 1e-4

@@ -188,13 +188,32 @@ def _gloo_grad_worker(rank, world, port, out_dir):
         _, want, _ = ov.ddpm_sample_vjp(spec, params, tables, xT, cond, noise, g, **kw)
         lo, hi = parallel.shard_bounds(n, rank, world)
         _, mine, _ = ov.ddpm_sample_vjp(spec, params, tables, xT[lo:hi], cond[lo:hi], noise[:, lo:hi], g[lo:hi], **kw)
-        to_t = lambda t: {k: to_t(v) if isinstance(v, dict) else torch.from_numpy(np.ascontiguousarray(v)) for k, v in t.items()}
+        to_t = lambda t: {k: to_t(v) if isinstance(v, dict) else torch.from_numpy(np.array(v, copy=True)) for k, v in t.items()}
         got = parallel.all_reduce_grads(to_t(mine))
         for path, v in parallel._leaves(got):
             ref = want
             for k in path:
                 ref = ref[k]
             assert np.allclose(v.numpy(), ref, rtol=1e-10, atol=1e-12), path
+        # the product's layout: leaves carved out of ONE flat buffer (_sampler.alloc_grad_tree) -> the collective runs on
+        # that buffer in place, the leaves (views of it) then hold the sums; no cat / copy-back
+        from flowrl_hip import _sampler
+        mine_t = to_t(mine)
+        paths = [path for path, _ in parallel._leaves(mine_t)]
+        flat_tree = _sampler.alloc_grad_tree(mine_t, paths, torch.device("cpu"))
+        for path, v in parallel._leaves(mine_t):
+            dst = flat_tree
+            for k in path:
+                dst = dst[k]
+            dst.copy_(v.to(torch.float32))
+        base = flat_tree.flat.data_ptr()
+        out = parallel.all_reduce_grads(flat_tree)
+        assert out is flat_tree and flat_tree.flat.data_ptr() == base
+        for path, v in parallel._leaves(flat_tree):
+            ref = want
+            for k in path:
+                ref = ref[k]
+            assert v.data_ptr() >= base and np.allclose(v.numpy(), ref, rtol=2e-5, atol=1e-6), path
         Path(out_dir, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()

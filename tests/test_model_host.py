@@ -70,3 +70,23 @@ def test_clip_known_answers_and_empty_optimizer():
     st = fm.TrainState.create(g, fm.adam(1e-3))
     with pytest.raises(KeyError):
         st.apply_gradients(g, {"a": {"kernel": g["a"]["kernel"]}})
+
+
+def test_continuous_tables_cache_survives_replace():
+    """`model.apply_gradient` replaces the model every optimizer step; the device-table cache of
+    ContinuousDDPM must travel with `replace()` (same schedule function / t_diffusion), and miss when they change."""
+    import numpy as np
+    import flowrl_hip as fh
+    from flowrl_hip.flow import ContinuousDDPM
+    net = fh.DDPMBackbone(noise_predictor=fh.MLP(hidden_dims=[256, 256], output_dim=3, activation="mish"),
+                          time_embedding=fh.LearnableFourierEmbedding(output_dim=64), cond_embedding=None)
+    inputs = (np.ones((1, 3)), np.zeros((1, 1)), np.ones((1, 5)))
+    m = ContinuousDDPM.create(net, 0, inputs, x_dim=3, steps=6, noise_schedule="cosine", device="cpu")
+    t1 = m._device_tables(6, m.t_schedule_n, False, "cpu")
+    m2 = m.replace(params=m.params)
+    assert m2 is not m
+    t2 = m2._device_tables(6, m.t_schedule_n, False, "cpu")
+    assert all(t1[k] is t2[k] for k in t1), "replace() dropped the table cache: every step would rebuild and re-upload it"
+    m3 = m2.replace(t_diffusion=[1e-3, 0.9])
+    t3 = m3._device_tables(6, m.t_schedule_n, False, "cpu")
+    assert t3["ts"] is not t1["ts"] and float(t3["ts"][-1]) != float(t1["ts"][-1])
