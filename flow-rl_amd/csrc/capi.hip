@@ -566,6 +566,7 @@ static void fill_bwd_args(const FrlDesc* desc, const FrlParams* params, const Pl
     a.ws_bf16 = ws + pl.off_bf16;
     a.bf_nxk = pl.bf_nxk; a.bf_cks = pl.bf_cks; a.bf_l0c = pl.bf_l0c; a.bf_ns = pl.bf_ns;
     b.hd = ws + bp16.off_hd; b.ad = ws + bp16.off_ad; b.gd = ws + bp16.off_gd; b.ge = ws + bp16.off_ge;
+    b.x0d = ws + bp16.off_x0d;
   } else {
     b.ws_wlt = ws + bp.off_wlt; b.ws_w0xq = ws + bp.off_w0xq;
     b.hd = ws + bp.off_hd; b.ad = ws + bp.off_ad; b.gd = ws + bp.off_gd; b.ge = ws + bp.off_ge;

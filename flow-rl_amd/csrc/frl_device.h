@@ -12,6 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int... I, typename F>
 __device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {

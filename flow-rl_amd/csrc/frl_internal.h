@@ -304,6 +304,7 @@ struct BArgs {
   const float* wt[FRL_MAX_HIDDEN - 1];  // transposed hidden kernels
   const float* ws_wlt; const float* ws_w0xq;
   float* hd; float* ad; float* gd; float* ge;
+  float* x0d;                     // bf16 variant: packed Dense_0 operands of every tile-step (BwdPlan16.off_x0d)
   float* grad_kernel[FRL_MAX_HIDDEN + 1]; float* grad_bias[FRL_MAX_HIDDEN + 1]; float* grad_tb;
   int Dp;                         // time rows of Dense_0 (skipped by the dW_0 scatter)
   long long n_ts;
@@ -343,13 +344,14 @@ int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order seco
 // (same chunk format: W_L^T, transposed hidden kernels top-down, Dense_0's x rows), so that the sweep cycles through
 // 2 * bf_ns chunks per step; then the stash, packed bf16 in the B-operand layout of the sweep
 // ([16 k-step pieces][64 lanes][8 bf16] = 16 KB per (wave-tile, step, layer)):
-//   Zd = bf16(z_l) (one copy: the sweep recomputes act'(z), the dW kernel act(z) from it), Gd = bf16(dL/dz_l), and
-//   Ge = bf16(dL/deps) (one 1 KB piece).
+//   Zd = bf16(z_l) (one copy: the sweep recomputes act'(z), the dW kernel act(z) from it), Gd = bf16(dL/dz_l),
+//   Ge = bf16(dL/deps) (one 1 KB piece), and X0d = the network INPUT of every step as the sweep's own packed Dense_0
+//   operands (x rows | cond k-steps: three 1 KB pieces in a 4 KB block): the X operand of dW_0.
 // Wave tiles are counted per 256-chain workgroup tile (8 each), so that every wave of the sweep owns a stash slot.
 struct BwdPlan16 {
   Plan f;
   long long n_wt, n_ts;
-  size_t off_img_b, off_hd, off_ad, off_gd, off_ge, off_tbs, total_floats;
+  size_t off_img_b, off_hd, off_ad, off_gd, off_ge, off_x0d, off_tbs, total_floats;
   int n_part; size_t off_part;
 };
 
@@ -365,6 +367,7 @@ inline int bwd16_plan_from_desc(const FrlDesc& d, BwdPlan16& b) {
   b.off_ad = b.off_hd;                            // (no separate act' stash)
   b.off_gd = take((size_t)b.n_ts * p.L * 4096);
   b.off_ge = take((size_t)b.n_ts * 256);
+  b.off_x0d = take((size_t)b.n_ts * 1024);
   b.off_tbs = take(time_bwd_scratch_floats(p.T, p.D));
   { const long long U = ((p.B + 31) / 32) * p.T, cus = device_cus(); b.n_part = (int)(U < cus ? U : cus); if (b.n_part < 1) b.n_part = 1; }
   b.off_part = take((size_t)b.n_part * dw_part_layout(p.L, p.T).stride);

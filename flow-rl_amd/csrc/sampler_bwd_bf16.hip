@@ -303,6 +303,12 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
           constexpr int ks = decltype(KI)::value;
           if constexpr (ks == 0) return bx; else return cbp[ks - 1];
         };
+        // the network input of this step as the dW kernel's X operand of Dense_0: the packed operands themselves
+        {
+          char* px0 = (char*)b.x0d + (size_t)ts * 4096;
+          st16(bx, px0, lane16, 0);
+          sfor<CKS>([&](auto CI) { constexpr int kc = decltype(CI)::value; st16(cbp[kc], px0, lane16, (1 + kc) * 1024); });
+        }
         layer_g<K0, 8>(b0, init_bias(s_tb + j * H), epi_fwd(bin, 0), next_chunk, lane16);
       }
       for (int l = 1; l < a.L; ++l) {
@@ -481,22 +487,96 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
 
 #if FRL_BWD16_PHASE == 0
 // ---- weight gradients ---------------------------------------------------------------------------------------------
-constexpr int DW_ROWB = 80;                    // bytes per LDS feature row: 32 chains x bf16 + 16 pad (conflict-free b128 reads)
-constexpr int DW_TILE = 256 * DW_ROWB;         // one operand tile
+// dW_l = sum over chains and steps of X_l (x) dL/dz_l.  The contraction index (chains) sits on the LANES of the stash
+// pieces while an MFMA wants it inside a lane, so the pieces pass through LDS — but nothing is scattered: a 16 KB stash
+// block goes into LDS by LDS-DMA (global_load_lds_dwordx4, per-lane SOURCE addresses permuted so that the linear LDS image
+// is the one the reads want) and the operands come back out with gfx950's transposing read ds_read_b64_tr_b16, which
+// hands each lane four CHAINS of one feature.  Image: the 16-byte chunk of chain c (0..31) and feature quad m = f / 4
+// holding features 4m..4m+3 and 4m+8..4m+11 (m & 2 == 0: exactly a stash chunk, piece ks = 2 (m >> 3) + ((m >> 2) & 1),
+// lane half m & 1) sits at slot
+//     (c & 3) | (m & 1) << 2 | ((m >> 2) & 1) << 3 | (c >> 2) << 4 | (m >> 3) << 7
+// so that the 32 lanes of a transposed read (4 chains x 32 features) cover one 256-byte bank row exactly: conflict-free.
+// X = act(z) is applied IN PLACE on the landed image (one ds_read_b128 / ds_write_b128 per chunk, lane-linear) one
+// tile-step ahead of the MFMAs; dL/dz needs nothing.  Bias gradients (column sums of dL/dz over chains) ride on the MFMA
+// pipe: an all-ones A operand against the same B operand.  All global traffic of the loop is LDS-DMA with counted vmcnt
+// waits (four 33 KB buffers, three tile-steps in flight, one s_barrier per tile-step).
+constexpr int DW_IMG = 16384;                  // one operand image: 32 chains x 256 features, bf16
+constexpr int DW_BUF = 2 * DW_IMG + 1024;      // X image | G image | the dL/deps piece as it is stashed (last layer)
+constexpr int DW_NBUF = 4;
 enum { DW_FIRST = 0, DW_HIDDEN = 1, DW_LAST = 2 };
 
-// feature held by element e of lane half s in stash piece ks (the B-operand layout of the sweep)
-__device__ __forceinline__ int piece_feature(int ks, int s, int e) { return 32 * (ks >> 1) + BF_ROWR(8 * (ks & 1) + e) + 4 * s; }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void lds_put_piece(char* tile, int ks, int li, int ls, u32x4 v) {
-  sfor<4>([&](auto WI) {
-    constexpr int w = decltype(WI)::value;
-    *(unsigned short*)(tile + piece_feature(ks, ls, 2 * w) * DW_ROWB + li * 2) = (unsigned short)(v[w] & 0xffffu);
-    *(unsigned short*)(tile + piece_feature(ks, ls, 2 * w + 1) * DW_ROWB + li * 2) = (unsigned short)(v[w] >> 16);
-  });
+// The operands of one 16-chain k-step, transposed out of the images: per 32-feature block two ds_read_b64_tr_b16 (chains
+// 8 h + 0..3 and 8 h + 4..7 of the lane's feature).  Inline asm, with its own lgkmcnt(0) at the end: behind the builtin
+// (__builtin_amdgcn_ds_read_tr16_b64_*) hipcc waits vmcnt(0) before the first read of every k-step — it cannot tell that
+// the LDS-DMA still in flight targets OTHER buffers — which would drain the three-deep DMA pipeline every tile-step.
+// pa / pb: this lane's address in the X / G image for block 0 of the wave and this k-step.
+template <int NM, int NN>
+__device__ __forceinline__ void tr_operands(unsigned pa, unsigned pb, u32x4 (&av)[NM], u32x4 (&bv)[NN]) {
+  u32x2 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h, b2l, b2h, b3l, b3h;
+  if constexpr (NM == 2 && NN == 4) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %12\n"
+        "ds_read_b64_tr_b16 %1, %12 offset:256\n"
+        "ds_read_b64_tr_b16 %2, %12 offset:2048\n"
+        "ds_read_b64_tr_b16 %3, %12 offset:2304\n"
+        "ds_read_b64_tr_b16 %4, %13\n"
+        "ds_read_b64_tr_b16 %5, %13 offset:256\n"
+        "ds_read_b64_tr_b16 %6, %13 offset:2048\n"
+        "ds_read_b64_tr_b16 %7, %13 offset:2304\n"
+        "ds_read_b64_tr_b16 %8, %13 offset:4096\n"
+        "ds_read_b64_tr_b16 %9, %13 offset:4352\n"
+        "ds_read_b64_tr_b16 %10, %13 offset:6144\n"
+        "ds_read_b64_tr_b16 %11, %13 offset:6400\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(b2l), "=&v"(b2h),
+          "=&v"(b3l), "=&v"(b3h)
+        : "v"(pa), "v"(pb)
+        : "memory");
+    av[0] = u32x4{a0l[0], a0l[1], a0h[0], a0h[1]}; av[1] = u32x4{a1l[0], a1l[1], a1h[0], a1h[1]};
+    bv[0] = u32x4{b0l[0], b0l[1], b0h[0], b0h[1]}; bv[1] = u32x4{b1l[0], b1l[1], b1h[0], b1h[1]};
+    bv[2] = u32x4{b2l[0], b2l[1], b2h[0], b2h[1]}; bv[3] = u32x4{b3l[0], b3l[1], b3h[0], b3h[1]};
+  } else if constexpr (NM == 2 && NN == 1) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %6\n"
+        "ds_read_b64_tr_b16 %1, %6 offset:256\n"
+        "ds_read_b64_tr_b16 %2, %6 offset:2048\n"
+        "ds_read_b64_tr_b16 %3, %6 offset:2304\n"
+        "ds_read_b64_tr_b16 %4, %7\n"
+        "ds_read_b64_tr_b16 %5, %7 offset:256\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h)
+        : "v"(pa), "v"(pb)
+        : "memory");
+    av[0] = u32x4{a0l[0], a0l[1], a0h[0], a0h[1]}; av[1] = u32x4{a1l[0], a1l[1], a1h[0], a1h[1]};
+    bv[0] = u32x4{b0l[0], b0l[1], b0h[0], b0h[1]};
+  } else {
+    static_assert(NM == 1 && NN == 1, "operand block shape");
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n"
+        "ds_read_b64_tr_b16 %1, %4 offset:256\n"
+        "ds_read_b64_tr_b16 %2, %5\n"
+        "ds_read_b64_tr_b16 %3, %5 offset:256\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a0l), "=&v"(a0h), "=&v"(b0l), "=&v"(b0h)
+        : "v"(pa), "v"(pb)
+        : "memory");
+    av[0] = u32x4{a0l[0], a0l[1], a0h[0], a0h[1]};
+    bv[0] = u32x4{b0l[0], b0l[1], b0h[0], b0h[1]};
+  }
+  __builtin_amdgcn_sched_barrier(0);      // no MFMA may move above the wait (guide 5.4 rule 18)
 }
 
-// h = act(z) of a stashed piece (8 bf16 z per lane), re-packed: the X operand of the next layer's weight gradient
+__device__ __forceinline__ void dma16_at(const char* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+// h = act(z) of a stashed chunk (8 bf16 z per lane), re-packed: the X operand of the next layer's weight gradient
 template <int ACT>
 __device__ __forceinline__ u32x4 act_piece(u32x4 z) {
   u32x4 o;
@@ -514,163 +594,184 @@ template <int KIND, int ACT>
 __device__ __forceinline__ void dw_layer(const BArgs& b, int lam, char* smem, long long u0, long long u1, long long n_wtv) {
   const KArgs& a = b.k;
   constexpr int H = 256;
-  constexpr int NM = (KIND == DW_HIDDEN) ? 2 : 1, NN = (KIND == DW_HIDDEN) ? 4 : 1;
+  // output blocks of a wave: hidden 2 x 4 of the 8 x 8; first layer (64 staged rows: x | cond k-steps | unused) 2 x 1;
+  // last layer 1 x 1 of the 8 x 1
+  constexpr int NM = (KIND == DW_LAST) ? 1 : 2, NN = (KIND == DW_HIDDEN) ? 4 : 1;
+  constexpr int NDMA = (KIND == DW_HIDDEN) ? 4 : 3;         // LDS-DMA instructions per wave and tile-step
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int A = a.A, C = a.C, T = a.T, L = a.L;
   const int mb0 = (KIND == DW_HIDDEN) ? 2 * (wave >> 1) : (KIND == DW_LAST ? wave : 0);
   const int nb0 = (KIND == DW_HIDDEN) ? 4 * (wave & 1) : (KIND == DW_FIRST ? wave : 0);
+  // the block whose column sums this wave carries (hidden: one of its four, so that the eight are spread over the waves)
+  constexpr bool kBiasAll = (KIND != DW_LAST);
+  const int nbias = (KIND == DW_HIDDEN) ? (wave >> 1) : 0;
+  const bool do_bias = kBiasAll || wave == 0;
 
-  f32x16 acc[NM][NN];
+  f32x16 acc[NM][NN], accb;
   sfor<NM>([&](auto MI) { sfor<NN>([&](auto NI) { sfor<16>([&](auto RI) {
     acc[decltype(MI)::value][decltype(NI)::value][decltype(RI)::value] = 0.0f; }); }); });
-  float bsum = 0.0f;
+  sfor<16>([&](auto RI) { accb[decltype(RI)::value] = 0.0f; });
   int jcur = -1;
   const DwPart dp = dw_part_layout(L, T);
   float* slot = b.part + (size_t)blockIdx.x * dp.stride;   // this workgroup's partial sums (frl_bwd_reduce_kernel adds the slots in order)
+  const int bcol = 32 * (nb0 + nbias) + li;                 // the column of this lane's bias / dL/dtb sums
   if constexpr (KIND == DW_FIRST) {
-    if (tid < 256) for (int j = 0; j < T; ++j) slot[dp.tb + (size_t)j * H + tid] = 0.0f;
+    // rows of steps this workgroup never visits stay zero; the same lane later overwrites the rows it does visit
+    if (lh == 0) for (int j = 0; j < T; ++j) slot[dp.tb + (size_t)j * H + bcol] = 0.0f;
   }
-
-  if (KIND == DW_LAST) {   // dL/deps occupies rows 0..15 of its block: rows 16..31 stay zero in both buffers
-    for (int idx = tid; idx < 2 * 32 * DW_ROWB / 4; idx += 512) {
-      const int bufi = idx / (32 * DW_ROWB / 4), off = idx - bufi * (32 * DW_ROWB / 4);
-      *(unsigned*)(smem + bufi * 2 * DW_TILE + DW_TILE + off * 4) = 0u;
+  if constexpr (KIND == DW_LAST) {
+    // dL/deps fills features 0..15 of block 0 (chunks with m < 4); features 16..31 (m = 4..7) stay zero in every buffer
+    for (int idx = tid; idx < DW_NBUF * 64; idx += 512) {
+      const int bufi = idx >> 6, k = idx & 63;
+      *(u32x4*)(smem + bufi * DW_BUF + DW_IMG + ((k & 7) | 8 | (k >> 3) << 4) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
   }
 
-  // staging registers of TWO tile-steps in flight (sets 0 / 1 by the parity of u - u0): the loads of tile-step u + 3 are
-  // issued when tile-step u + 1 is staged, two iterations (~ 2 x (16 MFMAs + transposes)) before they are needed — one
-  // iteration ahead left most of the HBM latency exposed (round 2: 0.93 ms at 4.2 TB/s)
-  u32x4 xr[2][2], gr[2][2];
-  float xv[2][2];
-  auto unit = [&](long long u, long long& ts, int& j, long long& wt) { j = (int)(u / n_wtv); wt = u - (long long)j * n_wtv; ts = wt * T + j; };
-  auto fetch = [&](long long u, auto SI) {
-    constexpr int st = decltype(SI)::value;
-    long long ts, wt; int j;
-    unit(u, ts, j, wt);
+  // per-lane parts of the addresses
+  //   DMA source inside a 16 KB stash block for LDS slot 64 i + lane: piece 2 (i >> 1) + ((lane >> 3) & 1), lane half
+  //   (lane >> 2) & 1, chain (lane & 3) | ((lane >> 4) & 3) << 2 | (i & 1) << 4
+  const unsigned g_lane = ((lane >> 3) & 1) * 1024 + ((lane >> 2) & 1) * 512 + ((lane & 3) + 4 * ((lane >> 4) & 3)) * 16;
+  //   transposed read: lane 4 q + p of the 16-lane group G supplies chain row q, feature quad 4 (G & 1) + p
+  const int trG = lane >> 4, trq = (lane >> 2) & 3, trp = lane & 3;
+  const unsigned tr_lane = 16 * trq + 64 * (trp & 1) + 8 * (trp >> 1) + 128 * (trG & 1) + 512 * (trG >> 1);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;      // LDS offset of the dynamic segment
+
+  // tile-steps are visited in order: (step, wave tile) advance incrementally (one 64-bit division per layer, not per tile-step)
+  int ij = (int)(u0 / n_wtv);
+  long long iwt = u0 - (long long)ij * n_wtv;
+  auto issue = [&](int bufi) {
+    const long long ts = iwt * T + ij;
+    if (++iwt == n_wtv) { iwt = 0; ++ij; }
+    char* buf = smem + bufi * DW_BUF;
     if constexpr (KIND == DW_FIRST) {
-      sfor<2>([&](auto EI) {
-        constexpr int k = decltype(EI)::value;
-        const int idx = tid + 512 * k, row = idx >> 5, c = idx & 31;
-        const long long chain = wt * 32 + c;
-        float v = 0.0f;
-        if (chain < a.B) {
-          if (row < A) v = b.xt_hist[((long long)j * a.B + chain) * A + row];
-          else if (row < A + C) v = a.cond[((a.particles == 1) ? chain : chain / a.particles) * C + (row - A)];
-        }
-        xv[st][k] = v;
-      });
+      const int i = wave & 3;              // 4 KB block (x | cond | cond | unused): waves 4..7 repeat waves 0..3 (uniform DMA count)
+      dma16_at((const char*)b.x0d + (size_t)ts * 4096 + (i >> 1) * 2048 + (i & 1) * 256 + g_lane, buf + i * 1024);
     } else {
-      const char* src = (const char*)b.hd + ((size_t)ts * L + (lam - 1)) * 16384 + lane * 16;
-      xr[st][0] = *(const u32x4*)(src + wave * 1024);
-      xr[st][1] = *(const u32x4*)(src + (wave + 8) * 1024);
+      const char* src = (const char*)b.hd + ((size_t)ts * L + (lam - 1)) * 16384 + g_lane;
+      sfor<2>([&](auto EI) { const int i = wave + 8 * decltype(EI)::value; dma16_at(src + (i >> 1) * 2048 + (i & 1) * 256, buf + i * 1024); });
     }
     if constexpr (KIND == DW_LAST) {
-      if (wave == 0) gr[st][0] = *(const u32x4*)((const char*)b.ge + (size_t)ts * 1024 + lane * 16);
+      dma16_at((const char*)b.ge + (size_t)ts * 1024 + lane * 16, buf + 2 * DW_IMG);      // every wave: the same 1 KB (uniform DMA count)
     } else {
-      const char* src = (const char*)b.gd + ((size_t)ts * L + lam) * 16384 + lane * 16;
-      gr[st][0] = *(const u32x4*)(src + wave * 1024);
-      gr[st][1] = *(const u32x4*)(src + (wave + 8) * 1024);
+      const char* src = (const char*)b.gd + ((size_t)ts * L + lam) * 16384 + g_lane;
+      sfor<2>([&](auto EI) { const int i = wave + 8 * decltype(EI)::value; dma16_at(src + (i >> 1) * 2048 + (i & 1) * 256, buf + DW_IMG + i * 1024); });
     }
   };
-  auto stage = [&](char* buf, auto SI) {
-    constexpr int st = decltype(SI)::value;
-    char* sX = buf;
-    char* sG = buf + DW_TILE;
-    if constexpr (KIND == DW_FIRST) {
+  // the landed X image of a buffer: z -> act(z) in place; last layer: the dL/deps piece into its image slots
+  auto finish = [&](int bufi) {
+    char* buf = smem + bufi * DW_BUF;
+    if constexpr (KIND != DW_FIRST) {
       sfor<2>([&](auto EI) {
-        constexpr int k = decltype(EI)::value;
-        const int idx = tid + 512 * k, row = idx >> 5, c = idx & 31;
-        *(unsigned short*)(sX + row * DW_ROWB + c * 2) = (unsigned short)(pack2(xv[st][k], 0.0f) & 0xffffu);
+        char* p = buf + (tid + 512 * decltype(EI)::value) * 16;
+        *(u32x4*)p = act_piece<ACT>(*(const u32x4*)p);
       });
-    } else {
-      lds_put_piece(sX, wave, li, lh, act_piece<ACT>(xr[st][0]));
-      lds_put_piece(sX, wave + 8, li, lh, act_piece<ACT>(xr[st][1]));
     }
     if constexpr (KIND == DW_LAST) {
-      if (wave == 0) lds_put_piece(sG, 0, li, lh, gr[st][0]);
-    } else {
-      lds_put_piece(sG, wave, li, lh, gr[st][0]);
-      lds_put_piece(sG, wave + 8, li, lh, gr[st][1]);
+      if (wave == 0) *(u32x4*)(buf + DW_IMG + ((li & 3) | lh << 2 | (li >> 2) << 4) * 16) = *(const u32x4*)(buf + 2 * DW_IMG + lane * 16);
     }
   };
-  typedef std::integral_constant<int, 0> S0;
-  typedef std::integral_constant<int, 1> S1;
+  const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  auto flush_tb = [&]() {
+    if (jcur >= 0 && lh == 0) slot[dp.tb + (size_t)jcur * H + bcol] = accb[0];
+    sfor<16>([&](auto RI) { accb[decltype(RI)::value] = 0.0f; });
+  };
 
-  if (u0 < u1) {
-    fetch(u0, S0{});
-    stage(smem, S0{});
-    if (u0 + 1 < u1) fetch(u0 + 1, S1{});
-    if (u0 + 2 < u1) fetch(u0 + 2, S0{});
+  const long long n = u1 - u0;
+  const bool mfma_first = (wave & 4) != 0;
+  int mj = (int)(u0 / n_wtv);                  // the MFMA loop's own (step, wave tile) position
+  long long mwt = u0 - (long long)mj * n_wtv;
+  if (n > 0) {
+    issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    if (n > 2) wait_vm_lgkm<2 * NDMA>(); else if (n > 1) wait_vm_lgkm<NDMA>(); else wait_vm_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    finish(0);
   }
-  __syncthreads();
-  auto body = [&](long long u, auto PI) {
-    constexpr int par = decltype(PI)::value;
-    char* buf = smem + par * 2 * DW_TILE;
-    const char* sX = buf;
-    const char* sG = buf + DW_TILE;
-    // ---- bias gradient: column sums of G ----
-    if (KIND != DW_LAST || tid < 32) {
-      if (tid < 256) {
-        if constexpr (KIND == DW_FIRST) {
-          const int j = (int)(u / n_wtv);
-          if (j != jcur) {
-            if (jcur >= 0) slot[dp.tb + (size_t)jcur * H + tid] = bsum;
-            bsum = 0.0f; jcur = j;
-          }
-        }
-        float s = 0.0f;
-        sfor<4>([&](auto VI) {
-          constexpr int v = decltype(VI)::value;
-          const u32x4 gv = *(const u32x4*)(sG + tid * DW_ROWB + v * 16);
-          sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; s += bf_lo(gv[w]) + bf_hi(gv[w]); });
-        });
-        bsum += s;
-      }
+  for (long long r = 0; r < n; ++r) {
+    const int cur = (int)(r & 3);
+    // tile-step r + 1 has landed (the newest NDMA instructions, tile-step r + 2's, may still be in flight); every wave
+    // has left iteration r - 1: its reads of buffer (r - 1) & 3 and its pass over buffer r & 3 are done
+    if (r + 2 < n) wait_vm_lgkm<NDMA>(); else wait_vm_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 3 < n) issue((int)((r + 3) & 3));
+    // The two halves of the workgroup run the iteration's two independent parts in opposite orders: waves w and w + 4
+    // share a SIMD, so while one is in its activation pass (VALU) the other is in its MFMAs — behind ONE barrier per
+    // tile-step both would otherwise do the same part at the same time (measured: 2.6 k cycles per tile-step, the sum).
+    if (!mfma_first && r + 1 < n) finish((int)((r + 1) & 3));
+    if constexpr (KIND == DW_FIRST) {
+      if (mj != jcur) { flush_tb(); jcur = mj; }
+      if (++mwt == n_wtv) { mwt = 0; ++mj; }
     }
-    // ---- contract over the 32 chains: two k-steps of 16 ----
+    const unsigned pX = lds0 + (unsigned)(cur * DW_BUF) + tr_lane + 2048u * mb0;      // LDS byte addresses
+    const unsigned pG = lds0 + (unsigned)(cur * DW_BUF + DW_IMG) + tr_lane + 2048u * nb0;
     sfor<2>([&](auto KI) {
       constexpr int kk = decltype(KI)::value;
       u32x4 av[NM], bv[NN];
-      sfor<NM>([&](auto MI) { constexpr int m = decltype(MI)::value; av[m] = *(const u32x4*)(sX + (32 * (mb0 + m) + li) * DW_ROWB + kk * 32 + lh * 16); });
-      sfor<NN>([&](auto NI) { constexpr int n = decltype(NI)::value; bv[n] = *(const u32x4*)(sG + (32 * (nb0 + n) + li) * DW_ROWB + kk * 32 + lh * 16); });
-      sfor<NM>([&](auto MI) { constexpr int m = decltype(MI)::value; sfor<NN>([&](auto NI) { constexpr int n = decltype(NI)::value;
-        acc[m][n] = mfma_bf(av[m], bv[n], acc[m][n]); }); });
+      tr_operands<NM, NN>(pX + 1024u * kk, pG + 1024u * kk, av, bv);
+      sfor<NM>([&](auto MI) { constexpr int m = decltype(MI)::value; sfor<NN>([&](auto NI) { constexpr int nn = decltype(NI)::value;
+        acc[m][nn] = mfma_bf(av[m], bv[nn], acc[m][nn]); }); });
+      if (do_bias) {
+        if constexpr (KIND == DW_HIDDEN) {
+          const u32x4 bb = nbias == 0 ? bv[0] : nbias == 1 ? bv[1] : nbias == 2 ? bv[2] : bv[3];
+          accb = mfma_bf(ones, bb, accb);
+        } else {
+          accb = mfma_bf(ones, bv[0], accb);
+        }
+      }
     });
-    // ---- next tile-step into the other buffer (its loads were issued two iterations ago); then tile-step u + 3's loads ----
-    if (u + 1 < u1) {
-      stage(smem + (par ^ 1) * 2 * DW_TILE, std::integral_constant<int, par ^ 1>{});
-      if (u + 3 < u1) fetch(u + 3, std::integral_constant<int, par ^ 1>{});
-    }
-    __syncthreads();
-  };
-  for (long long u = u0; u < u1; u += 2) {
-    body(u, S0{});
-    if (u + 1 < u1) body(u + 1, S1{});
+    if (mfma_first && r + 1 < n) finish((int)((r + 1) & 3));
   }
 
   // ---- flush: partial tile into this workgroup's slot (plain stores; the second stage adds the slots in order) ----
-  float* pk = slot + (KIND == DW_FIRST ? dp.k0 : KIND == DW_HIDDEN ? dp.kh + (size_t)(lam - 1) * 65536 : dp.kl);
-  constexpr int PCOL = (KIND == DW_LAST) ? 32 : H;
-  sfor<NM>([&](auto MI) {
-    constexpr int m = decltype(MI)::value;
-    sfor<NN>([&](auto NI) {
-      constexpr int n = decltype(NI)::value;
+  if constexpr (KIND == DW_FIRST) {
+    // staged rows of the slot: x rows 0..A-1, then the condition features; the operand rows are x (piece 0: row
+    // ROWR(e) + 4 s = the feature index itself), then cond k-step kc at 16 (1 + kc) + [8 (e >> 2) + 4 s + (e & 3)] for
+    // condition feature 16 kc + 8 s + e
+    float* pk = slot + dp.k0;
+    sfor<NM>([&](auto MI) {
+      constexpr int m = decltype(MI)::value;
       sfor<16>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
-        const int in = 32 * (mb0 + m) + BF_ROWR(r) + 4 * lh;
-        const int out = 32 * (nb0 + n) + li;
-        pk[(size_t)in * PCOL + out] = acc[m][n][r];
+        const int in = 32 * m + BF_ROWR(r) + 4 * lh;
+        int row = -1;
+        if (in < 16) { if (in < A) row = in; }
+        else if (in < 48) {
+          const int kc = (in >> 4) - 1, w = in & 15;
+          const int cf = 16 * kc + 8 * ((w >> 2) & 1) + 4 * ((w >> 3) & 1) + (w & 3);
+          if (cf < C) row = A + cf;
+        }
+        if (row >= 0) pk[(size_t)row * H + 32 * nb0 + li] = acc[m][0][r];
       });
     });
-  });
-  if constexpr (KIND == DW_FIRST) {
-    if (tid < 256 && jcur >= 0) slot[dp.tb + (size_t)jcur * H + tid] = bsum;
+    flush_tb();
   } else {
-    if (tid < 256) slot[dp.bias + (size_t)(lam - 1) * 256 + tid] = (KIND == DW_LAST && tid >= 32) ? 0.0f : bsum;
+    float* pk = slot + (KIND == DW_HIDDEN ? dp.kh + (size_t)(lam - 1) * 65536 : dp.kl);
+    constexpr int PCOL = (KIND == DW_LAST) ? 32 : H;
+    sfor<NM>([&](auto MI) {
+      constexpr int m = decltype(MI)::value;
+      sfor<NN>([&](auto NI) {
+        constexpr int nn = decltype(NI)::value;
+        sfor<16>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int in = 32 * (mb0 + m) + BF_ROWR(r) + 4 * lh;
+          const int out = 32 * (nb0 + nn) + li;
+          pk[(size_t)in * PCOL + out] = acc[m][nn][r];
+        });
+      });
+    });
+    if constexpr (KIND == DW_HIDDEN) {
+      if ((wave & 1) * 0 == 0 && lh == 0) slot[dp.bias + (size_t)(lam - 1) * 256 + bcol] = accb[0];
+    } else {
+      if (tid < 256) slot[dp.bias + (size_t)(lam - 1) * 256 + tid] = (tid < 32) ? accb[0] : 0.0f;   // tid < 32: wave 0, lane half 0
+    }
   }
-  __syncthreads();
+  wait_vm_lgkm<0>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int ACT>
@@ -689,7 +790,7 @@ frl_bwd_dw_bf16_kernel(const BArgs b) {
 template <int ACT>
 static int launch_dw16_inst(const BArgs& b, hipStream_t stream) {
   const int g2 = b.n_part;                                // one partial slot per workgroup (BwdPlan16.n_part)
-  const size_t lds2 = 4 * (size_t)DW_TILE;
+  const size_t lds2 = (size_t)DW_NBUF * DW_BUF;
   auto kern = frl_bwd_dw_bf16_kernel<ACT>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FRL_EHIP; }

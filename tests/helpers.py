@@ -9,6 +9,16 @@ import numpy as np
 import flowrl_oracle as orc
 
 
+# per-case parity margins of a GPU session (tests/conftest.py writes them to gpurun_out/parity_margins.json at session end;
+# a copy is committed as profiles/rNN_parity_margins.json): how close to its bar each case sits
+MARGINS: list = []
+
+
+def record_margin(suite: str, case: str, build: str, **metrics):
+    MARGINS.append({"suite": suite, "case": case, "build": build,
+                    **{k: (float(v) if v is not None else None) for k, v in metrics.items()}})
+
+
 @dataclass
 class Case:
     name: str

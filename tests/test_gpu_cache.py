@@ -113,7 +113,7 @@ def test_prepared_workspace_serves_any_batch_size(cond_embed):
         case = H.Case("dql", "ddpm", A=3, S=11, T=3, B=70016)
     params, xT, cond, noise = H.make_inputs(case)
     model = H.product_model(case, params)
-    dev = torch.device("cuda")
+    dev = torch.device("cuda", torch.cuda.current_device())
     x, c, nz = (torch.from_numpy(v).to(dev) for v in (xT, cond, noise))
     keep = []
     kind = _lib.FRL_KIND_DDPM if case.kind == "ddpm" else _lib.FRL_KIND_CDDPM

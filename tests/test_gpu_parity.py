@@ -74,6 +74,11 @@ def _check(case, history=True, slack=4.0):
         assert ee <= tol_eps and ex <= tol_state, msg
         assert H.rms_err(xh, refx) <= tol_rms, msg
     print(msg)
+    H.record_margin("forward_f32", case.name, TILE, x0_max=e0, x0_rms=H.rms_err(x0, ref0), bar_state=tol_state, bar_rms=tol_rms,
+                    float32_oracle_max=e32, float32_oracle_rms=r32, x0_frac_of_bar=e0 / tol_state,
+                    first_eval_max=(H.rel_err(eh[0], refe[0]) if history else None), first_eval_bar=TOL,
+                    first_eval_frac_of_bar=(H.rel_err(eh[0], refe[0]) / TOL if history else None),
+                    eps_hist_max=(H.rel_err(eh, refe) if history else None), bar_eps=tol_eps)
     assert e0 <= tol_state and H.rms_err(x0, ref0) <= tol_rms, msg
 
 
@@ -105,6 +110,12 @@ def test_ddpm_hopper_ragged():
 def test_ddpm_toy2d():
     # cfg1: toy2d (obs = zeros(1), act 2, linear schedule, T=20, clip off)
     c = H.Case("cfg1-toy2d", "ddpm", A=2, S=1, T=20, B=512, schedule="linear", clip=False, x_min=-4.0, x_max=4.0)
+    _check(c)
+
+
+def test_ddpm_toy2d_cfg1_full_batch():
+    # cfg1 at BASELINE's stated batch (4096 chains, T = 20) against the float64 oracle (seconds of numpy)
+    c = H.Case("cfg1-toy2d-B4096", "ddpm", A=2, S=1, T=20, B=4096, schedule="linear", clip=False, x_min=-4.0, x_max=4.0, seed=77)
     _check(c)
 
 
@@ -264,6 +275,8 @@ def test_against_committed_golden(case):
     x0, xh, eh = H.product_run(case, model, z["xT"], z["cond"], z["noise"], history=True)
     msg = f"{case.name}: x0 {H.rel_err(x0, z['x0']):.2e} xt {H.rel_err(xh, z['xt_hist']):.2e} eps {H.rel_err(eh, z['eps_hist']):.2e}"
     print(msg)
+    H.record_margin("forward_f32_golden", case.name, TILE, x0_max=H.rel_err(x0, z["x0"]), bar_state=2e-5, x0_frac_of_bar=H.rel_err(x0, z["x0"]) / 2e-5,
+                    eps_hist_max=H.rel_err(eh, z["eps_hist"]), bar_eps=TOL, x0_rms=H.rms_err(x0, z["x0"]), bar_rms=2e-6)
     assert H.rel_err(x0, z["x0"]) <= 2e-5 and H.rel_err(xh, z["xt_hist"]) <= 2e-5 and H.rel_err(eh, z["eps_hist"]) <= TOL, msg
     assert H.rms_err(x0, z["x0"]) <= 2e-6, msg
 

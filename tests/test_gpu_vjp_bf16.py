@@ -82,6 +82,8 @@ def _run(case, stash=False):
     w_ex = max(rows, key=lambda r: r[2])
     print(f"{case.name}: worst leaf vs emulation (same states) {w_emu[1]:.2e} ({w_emu[0]}); vs exact {w_ex[2]:.2e} ({w_ex[0]}), "
           f"emulation's own {w_ex[3]:.2e}{'' if smooth else '  [non-smooth loss: clip / relu masks flip]'}")
+    H.record_margin("vjp_bf16", case.name, "stash" if stash else "recompute", leaf_l2_vs_emulation=w_emu[1], bar_vs_emulation=TOL_EMU,
+                    emulation_frac_of_bar=w_emu[1] / TOL_EMU, leaf_l2_vs_exact=w_ex[2], emulation_own_vs_exact=w_ex[3])
     for k, e_emu, e_ex, e_own in rows:
         assert e_emu <= TOL_EMU, f"{case.name}: {k} vs emulation {e_emu:.2e}"
         assert e_ex <= 1.5 * e_own + (2e-3 if smooth else 2e-2), f"{case.name}: {k} vs exact {e_ex:.2e} (emulation {e_own:.2e})"
