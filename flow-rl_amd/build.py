@@ -25,7 +25,7 @@ OUT = HERE / "flowrl_hip" / "libflowrl_hip.so"
 ARCH = "gfx950"
 # (source, object stem, extra defines); the register-streamed sampler is one translation unit per activation
 SOURCES = [("capi.hip", "capi", []), ("prepare.hip", "prepare", []),
-           ("cond_embed.hip", "cond_embed", []), ("critic_select.hip", "critic_select", []), ("time_bwd.hip", "time_bwd", []), ("rng.hip", "rng", []), ("net_eval.hip", "net_eval", []),
+           ("cond_embed.hip", "cond_embed", []), ("critic_select.hip", "critic_select", []), ("time_bwd.hip", "time_bwd", []), ("rng.hip", "rng", []), ("net_eval.hip", "net_eval", []), ("net_vjp_layered.hip", "net_vjp_layered", []),
            ("sampler_bf16.hip", "sampler_bf16", ["-fno-slp-vectorize"]),
            ] + [("sampler_bwd_bf16.hip", f"sampler_bwd_bf16_p{p}", ["-fno-slp-vectorize", f"-DFRL_BWD16_PHASE={p}"]) for p in range(3)] + \
           [("sampler_bwd.hip", f"sampler_bwd_p{p}", [f"-DFRL_BWD_PHASE={p}"]) for p in range(3)] + [("sampler_bwd_lat.hip", "sampler_bwd_lat", [])] + \

@@ -983,20 +983,37 @@ struct EvalBwdPlan {
   BwdPlan bp;           // stash, transposed images, dW slots behind them
   int Cp;               // rows of u = [tfeat | cond] = Dp + C
   size_t off_cfeat, off_u, off_zt, off_du, off_tsc, off_ceb, total_floats;
+  int layered;          // 1: layer-by-layer path (csrc/net_vjp_layered.hip): 512-wide, LayerNorm, residual predictors, wide inputs
+  LayeredPlan lp;
+  size_t off_lp;        // its workspace region
 };
 
 static int eval_bwd_plan(const FrlDesc* desc, EvalBwdPlan& q) {
   int rc = eval_plan(desc, q.e);
   if (rc != FRL_OK) return rc;
   const Plan& pl = q.e.pl;
-  if (pl.H != 256 || pl.TR != 32) { set_error("single-evaluation VJP: 256-wide predictors only"); return FRL_EUNSUPPORTED; }
-  if (desc->layer_norm) { set_error("single-evaluation VJP: LayerNorm backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
-  if (desc->backbone != FRL_BACKBONE_MLP) { set_error("single-evaluation VJP: residual backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   q.Cp = q.e.Dp + q.e.C;
-  if (pl.AR > 12 || pl.A + q.Cp > 224) { set_error("single-evaluation VJP: x_dim <= 24 and x_dim + time_dim + cond_dim <= 224 required (got %d, %d)", pl.A, q.Cp); return FRL_EUNSUPPORTED; }
+  q.layered = (pl.H != 256 || pl.TR != 32 || desc->layer_norm != 0 || desc->backbone != FRL_BACKBONE_MLP || pl.AR > 12 || pl.A + q.Cp > 224) ? 1 : 0;
   if (desc->time_embed != FRL_TEMB_NONE && desc->time_dim > 128) { set_error("single-evaluation VJP: time_dim <= 128"); return FRL_EUNSUPPORTED; }
+  if (q.layered) {
+    // everything the fused sweep does not carry: forward tables are not needed, only the per-sample rows and the layer buffers
+    rc = layered_plan(*desc, q.Cp, q.lp);
+    if (rc != FRL_OK) return rc;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    const int D = desc->time_embed == FRL_TEMB_NONE ? 0 : desc->time_dim;
+    q.off_cfeat = take(desc->cond_embed ? (size_t)desc->n_states * COND_EMBED_DIM : 0);
+    q.off_u = take((size_t)pl.B * q.Cp);
+    q.off_zt = 0; q.off_du = 0;
+    q.off_tsc = take(time_bwd_samples_scratch_floats(pl.B, D, desc->time_embed == FRL_TEMB_FOURIER));
+    q.off_ceb = take(desc->cond_embed ? (size_t)desc->n_states * 3 * COND_EMBED_DIM : 0);
+    q.off_lp = take(q.lp.total_floats);
+    q.total_floats = o;
+    return FRL_OK;
+  }
   q.bp.f = pl;
   bwd_plan_finish(q.bp, 0, desc->n_states, pl.A + q.Cp);
+  q.off_lp = 0;
   size_t o = q.bp.total_floats;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
   const int D = desc->time_embed == FRL_TEMB_NONE ? 0 : desc->time_dim;
@@ -1040,8 +1057,17 @@ size_t frl_net_eval_bwd_workspace_bytes(const FrlDesc* desc) {
 }
 
 static int eval_check_params(const FrlDesc* desc, const FrlParams* params) {
-  for (int l = 0; l <= desc->n_hidden; ++l)
+  const int n_dense = desc->backbone != FRL_BACKBONE_MLP ? 1 : desc->n_hidden;
+  for (int l = 0; l <= n_dense; ++l)
     if (params->kernel[l] == nullptr || params->bias[l] == nullptr) { set_error("params.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->backbone != FRL_BACKBONE_MLP) {
+    ResArgs ra;
+    int rc = fill_res_args(desc, params, ra);
+    if (rc != FRL_OK) return rc;
+  } else if (desc->layer_norm) {
+    for (int l = 0; l < desc->n_hidden; ++l)
+      if (params->ln_scale[l] == nullptr || params->ln_bias[l] == nullptr) { set_error("params.ln_scale/ln_bias[%d] is NULL (desc.layer_norm)", l); return FRL_EINVAL; }
+  }
   if (desc->time_embed != FRL_TEMB_NONE) {
     for (int k = 0; k < 2; ++k)
       if (params->tmlp_kernel[k] == nullptr || params->tmlp_bias[k] == nullptr) { set_error("params.tmlp_kernel/bias[%d] is NULL", k); return FRL_EINVAL; }
@@ -1070,6 +1096,18 @@ int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEv
   if (rc != FRL_OK) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
   float* ws = (float*)workspace;
+  if (q.layered) {
+    const float* cond = bufs->cond;
+    if (desc->cond_embed) {
+      rc = launch_cond_embed(desc->act, bufs->cond, desc->n_states, desc->cond_in_dim, params->cond_kernel[0], params->cond_bias[0],
+                             params->cond_kernel[1], params->cond_bias[1], ws + q.off_cfeat, stream);
+      if (rc != FRL_OK) return rc;
+      cond = ws + q.off_cfeat;
+    }
+    rc = launch_time_rows(*desc, *params, bufs->t, cond, q.e.C, ws + q.off_u, pl.B, stream);
+    if (rc != FRL_OK) return rc;
+    return launch_layered_fwd(*desc, *params, q.lp, ws + q.off_lp, bufs->x, ws + q.off_u, bufs->out, stream);
+  }
   PArgs pa;
   memset(&pa, 0, sizeof(pa));
   for (int l = 0; l <= pl.L; ++l) { pa.p.kernel[l] = params->kernel[l]; pa.p.bias[l] = params->bias[l]; }
@@ -1109,8 +1147,21 @@ int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEval
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
   rc = eval_check_params(desc, params);
   if (rc != FRL_OK) return rc;
-  for (int l = 0; l <= desc->n_hidden; ++l)
+  const int n_dense = desc->backbone != FRL_BACKBONE_MLP ? 1 : desc->n_hidden;
+  for (int l = 0; l <= n_dense; ++l)
     if (bufs->grad_kernel[l] == nullptr || bufs->grad_bias[l] == nullptr) { set_error("bufs.grad_kernel / grad_bias[%d] is NULL", l); return FRL_EINVAL; }
+  if (desc->backbone != FRL_BACKBONE_MLP) {
+    const bool simba = desc->backbone == FRL_BACKBONE_SIMBA;
+    for (int i = 0; i < desc->n_hidden; ++i) {
+      for (int k = 0; k < 2; ++k)
+        if (bufs->grad_res_kernel[i][k] == nullptr || bufs->grad_res_bias[i][k] == nullptr) { set_error("bufs.grad_res_kernel / grad_res_bias[%d][%d] is NULL", i, k); return FRL_EINVAL; }
+      if ((simba || desc->layer_norm) && (bufs->grad_res_ln_scale[i] == nullptr || bufs->grad_res_ln_bias[i] == nullptr)) { set_error("bufs.grad_res_ln_scale / grad_res_ln_bias[%d] is NULL", i); return FRL_EINVAL; }
+    }
+    if (simba && (bufs->grad_final_ln_scale == nullptr || bufs->grad_final_ln_bias == nullptr)) { set_error("bufs.grad_final_ln_scale / grad_final_ln_bias is NULL (Simba)"); return FRL_EINVAL; }
+  } else if (desc->layer_norm) {
+    for (int l = 0; l < desc->n_hidden; ++l)
+      if (bufs->grad_ln_scale[l] == nullptr || bufs->grad_ln_bias[l] == nullptr) { set_error("bufs.grad_ln_scale / grad_ln_bias[%d] is NULL (desc.layer_norm)", l); return FRL_EINVAL; }
+  }
   if (desc->time_embed != FRL_TEMB_NONE) {
     for (int k = 0; k < 2; ++k)
       if (bufs->grad_tmlp_kernel[k] == nullptr || bufs->grad_tmlp_bias[k] == nullptr) { set_error("bufs.grad_tmlp_kernel / grad_tmlp_bias[%d] is NULL", k); return FRL_EINVAL; }
@@ -1121,6 +1172,14 @@ int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEval
       if (bufs->grad_cond_kernel[k] == nullptr || bufs->grad_cond_bias[k] == nullptr) { set_error("bufs.grad_cond_kernel / grad_cond_bias[%d] is NULL", k); return FRL_EINVAL; }
   hipStream_t stream = (hipStream_t)hip_stream;
   float* ws = (float*)workspace;
+  float* du = ws + q.off_du;
+  int du_stride = q.Cp;
+  if (q.layered) {
+    rc = launch_layered_bwd(*desc, *params, q.lp, ws + q.off_lp, bufs->g_out, *bufs, bufs->g_x, stream);
+    if (rc != FRL_OK) return rc;
+    du = ws + q.off_lp + q.lp.off_dinp + desc->x_dim;          // dL/dinp = [dL/dx | dL/du], row stride K0
+    du_stride = q.lp.K0;
+  } else {
   rc = launch_prepare_bwd(*params, q.bp, ws, stream);          // transposed hidden kernels, W_L^T, packed x rows of Dense_0
   if (rc != FRL_OK) return rc;
   BArgs b;
@@ -1132,13 +1191,13 @@ int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEval
   rc = launch_sampler_bwd(q.e.d, b, 2, stream);               // backward sweep from the stash + dW + fixed-order reduce
   if (rc != FRL_OK) return rc;
   // dL/du = dL/dz_0 . kernel_0[A:]^T per sample, then the two branches that produced u = [tfeat | cond]
-  float* du = ws + q.off_du;
   rc = launch_eval_du(b, params->kernel[0] + (size_t)desc->x_dim * pl.H, q.Cp, du, stream);
   if (rc != FRL_OK) return rc;
+  }
   if (desc->time_embed != FRL_TEMB_NONE) {
     TimeBwdSampleArgs ta;
     memset(&ta, 0, sizeof(ta));
-    ta.t = bufs->t; ta.du = du; ta.du_stride = q.Cp;
+    ta.t = bufs->t; ta.du = du; ta.du_stride = du_stride;
     ta.time_kernel = params->time_kernel; ta.tk0 = params->tmlp_kernel[0]; ta.tb0 = params->tmlp_bias[0];
     ta.tk1 = params->tmlp_kernel[1]; ta.tb1 = params->tmlp_bias[1];
     ta.scratch = ws + q.off_tsc;
@@ -1150,7 +1209,7 @@ int frl_net_eval_bwd(const FrlDesc* desc, const FrlParams* params, const FrlEval
   }
   if (desc->cond_embed) {
     rc = launch_cond_embed_bwd(desc->act, bufs->cond, desc->n_states, desc->particles, desc->cond_in_dim, params->cond_kernel[0],
-                               params->cond_bias[0], params->cond_kernel[1], params->cond_bias[1], du + q.e.Dp, q.Cp, ws + q.off_ceb,
+                               params->cond_bias[0], params->cond_kernel[1], params->cond_bias[1], du + q.e.Dp, du_stride, ws + q.off_ceb,
                                bufs->grad_cond_kernel[0], bufs->grad_cond_bias[0], bufs->grad_cond_kernel[1], bufs->grad_cond_bias[1], stream);
     if (rc != FRL_OK) return rc;
   }

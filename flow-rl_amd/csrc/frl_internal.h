@@ -339,6 +339,21 @@ inline size_t time_bwd_samples_scratch_floats(long long B, int D, bool fourier) 
 }
 int launch_bwd_reduce(const BArgs& b, hipStream_t stream);   // fixed-order second stage of the weight-gradient reduction
 
+// ---- layer-by-layer single-evaluation VJP (csrc/net_vjp_layered.hip): 512-wide, LayerNorm and residual predictors ----
+struct LayeredPlan {
+  long long B;
+  int A, Cp, K0, H, L, Wmax, res, splits;
+  size_t off_inp, off_dinp;
+  size_t off_z[FRL_MAX_HIDDEN + 1], off_h[FRL_MAX_HIDDEN], off_e[FRL_MAX_HIDDEN], off_a[FRL_MAX_HIDDEN], off_hf;
+  size_t off_g0, off_g1, off_g2, off_pdy, off_pxh, off_cs, off_part;
+  size_t total_floats;
+};
+int layered_plan(const FrlDesc& d, int Cp, LayeredPlan& q);
+int launch_layered_fwd(const FrlDesc& d, const FrlParams& p, const LayeredPlan& q, float* ws, const float* x, const float* u, float* out,
+                       hipStream_t stream);
+int launch_layered_bwd(const FrlDesc& d, const FrlParams& p, const LayeredPlan& q, float* ws, const float* g_out, const FrlEvalBwdBufs& gb,
+                       float* g_x, hipStream_t stream);
+
 // ---- backward, bf16-MFMA variant (csrc/sampler_bwd_bf16.hip) -------------------------------------------------
 // Workspace = the forward plan with its bf16 weight stream image, DIRECTLY followed by the backward stream image
 // (same chunk format: W_L^T, transposed hidden kernels top-down, Dense_0's x rows), so that the sweep cycles through

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FRL_ABI_VERSION = 5
+FRL_ABI_VERSION = 6
 FRL_MAX_HIDDEN = 8
 
 FRL_KIND_DDPM, FRL_KIND_CDDPM, FRL_KIND_CNF = 0, 1, 2
@@ -90,7 +90,11 @@ class FrlEvalBwdBufs(C.Structure):
     _fields_ = [("x", _fp), ("cond", _fp), ("t", _fp), ("g_out", _fp), ("g_x", _fp),
                 ("grad_kernel", _fp * (FRL_MAX_HIDDEN + 1)), ("grad_bias", _fp * (FRL_MAX_HIDDEN + 1)),
                 ("grad_tmlp_kernel", _fp * 2), ("grad_tmlp_bias", _fp * 2), ("grad_time_kernel", _fp),
-                ("grad_cond_kernel", _fp * 2), ("grad_cond_bias", _fp * 2)]
+                ("grad_cond_kernel", _fp * 2), ("grad_cond_bias", _fp * 2),
+                ("grad_ln_scale", _fp * FRL_MAX_HIDDEN), ("grad_ln_bias", _fp * FRL_MAX_HIDDEN),
+                ("grad_res_kernel", (_fp * 2) * FRL_MAX_HIDDEN), ("grad_res_bias", (_fp * 2) * FRL_MAX_HIDDEN),
+                ("grad_res_ln_scale", _fp * FRL_MAX_HIDDEN), ("grad_res_ln_bias", _fp * FRL_MAX_HIDDEN),
+                ("grad_final_ln_scale", _fp), ("grad_final_ln_bias", _fp)]
 
 
 FRL_NOISE_DDPM, FRL_NOISE_CDDPM_LINEAR, FRL_NOISE_CDDPM_COSINE, FRL_NOISE_FLOW = 0, 1, 2, 3

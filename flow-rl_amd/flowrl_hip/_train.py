@@ -11,8 +11,8 @@ import torch
 
 from . import _lib
 from . import random as _random
-from .module import LearnableFourierEmbedding
-from ._sampler import _f32c, _split_condition, _workspace, build_desc, build_params, check_param_shapes
+from .module import LearnableFourierEmbedding, Simba, is_residual
+from ._sampler import _f32c, _split_condition, _workspace, alloc_grad_tree, build_desc, build_params, check_param_shapes
 
 
 def net_eval(network, params: Dict, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None, *,
@@ -133,28 +133,56 @@ def net_eval_vjp(ctx: EvalVjpContext, g_out: torch.Tensor, want_gx: bool = False
     if g_x is not None:
         bufs.g_x = g_x.data_ptr()
     pname = network.predictor_name
-    grads: Dict = {pname: {}}
-    for i in range(len(network.predictor.hidden_dims) + 1):
-        gk, gb = _grad_like(params[pname][f"Dense_{i}"])
-        grads[pname][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
-        bufs.grad_kernel[i], bufs.grad_bias[i] = gk.data_ptr(), gb.data_ptr()
+    pred = network.predictor
+    n = len(pred.hidden_dims)
+    res = is_residual(pred)
     te = network.time_embedding
+    # every gradient leaf is a view of one flat f32 buffer (_sampler.GradTree), as in the chain VJP
+    if res:
+        paths = [(pname, f"Dense_{i}", w) for i in range(2) for w in ("kernel", "bias")]
+        for i in range(n):
+            blk = f"{pred.block_name}_{i}"
+            paths += [(pname, blk, f"Dense_{k}", w) for k in range(2) for w in ("kernel", "bias")]
+            if pred.layer_norm:
+                paths += [(pname, blk, "LayerNorm_0", w) for w in ("scale", "bias")]
+        if isinstance(pred, Simba):
+            paths += [(pname, "LayerNorm_0", w) for w in ("scale", "bias")]
+    else:
+        paths = [(pname, f"Dense_{i}", w) for i in range(n + 1) for w in ("kernel", "bias")]
+        if pred.layer_norm:
+            paths += [(pname, f"LayerNorm_{i}", w) for i in range(n) for w in ("scale", "bias")]
     if te is not None:
-        grads["MLP_0"] = {}
-        for i in range(2):
-            gk, gb = _grad_like(params["MLP_0"][f"Dense_{i}"])
-            grads["MLP_0"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
-            bufs.grad_tmlp_kernel[i], bufs.grad_tmlp_bias[i] = gk.data_ptr(), gb.data_ptr()
+        paths += [("MLP_0", f"Dense_{i}", w) for i in range(2) for w in ("kernel", "bias")]
         if isinstance(te, LearnableFourierEmbedding):
-            gw = torch.empty_like(params["time_embedding"]["kernel"], dtype=torch.float32, memory_format=torch.contiguous_format)
-            grads["time_embedding"] = {"kernel": gw}
-            bufs.grad_time_kernel = gw.data_ptr()
+            paths.append(("time_embedding", "kernel"))
     if network.cond_embedding is not None:
-        grads["cond_embedding"] = {}
+        paths += [("cond_embedding", f"Dense_{i}", w) for i in range(2) for w in ("kernel", "bias")]
+    grads = alloc_grad_tree(params, paths, device)
+    gp = grads[pname]
+    for i in range(2 if res else n + 1):
+        bufs.grad_kernel[i], bufs.grad_bias[i] = gp[f"Dense_{i}"]["kernel"].data_ptr(), gp[f"Dense_{i}"]["bias"].data_ptr()
+    if res:
+        for i in range(n):
+            blk = gp[f"{pred.block_name}_{i}"]
+            for k in range(2):
+                bufs.grad_res_kernel[i][k], bufs.grad_res_bias[i][k] = blk[f"Dense_{k}"]["kernel"].data_ptr(), blk[f"Dense_{k}"]["bias"].data_ptr()
+            if pred.layer_norm:
+                bufs.grad_res_ln_scale[i], bufs.grad_res_ln_bias[i] = blk["LayerNorm_0"]["scale"].data_ptr(), blk["LayerNorm_0"]["bias"].data_ptr()
+        if isinstance(pred, Simba):
+            bufs.grad_final_ln_scale, bufs.grad_final_ln_bias = gp["LayerNorm_0"]["scale"].data_ptr(), gp["LayerNorm_0"]["bias"].data_ptr()
+    elif pred.layer_norm:
+        for i in range(n):
+            bufs.grad_ln_scale[i], bufs.grad_ln_bias[i] = gp[f"LayerNorm_{i}"]["scale"].data_ptr(), gp[f"LayerNorm_{i}"]["bias"].data_ptr()
+    if te is not None:
         for i in range(2):
-            gk, gb = _grad_like(params["cond_embedding"][f"Dense_{i}"])
-            grads["cond_embedding"][f"Dense_{i}"] = {"kernel": gk, "bias": gb}
-            bufs.grad_cond_kernel[i], bufs.grad_cond_bias[i] = gk.data_ptr(), gb.data_ptr()
+            g = grads["MLP_0"][f"Dense_{i}"]
+            bufs.grad_tmlp_kernel[i], bufs.grad_tmlp_bias[i] = g["kernel"].data_ptr(), g["bias"].data_ptr()
+        if isinstance(te, LearnableFourierEmbedding):
+            bufs.grad_time_kernel = grads["time_embedding"]["kernel"].data_ptr()
+    if network.cond_embedding is not None:
+        for i in range(2):
+            g = grads["cond_embedding"][f"Dense_{i}"]
+            bufs.grad_cond_kernel[i], bufs.grad_cond_bias[i] = g["kernel"].data_ptr(), g["bias"].data_ptr()
     stream = torch.cuda.current_stream(device).cuda_stream
     with torch.cuda.device(device):
         rc = lib.frl_net_eval_bwd(C.byref(ctx.desc), C.byref(ctx.fparams), C.byref(bufs), ctx.ws.data_ptr(), ctx.ws.numel(), stream)

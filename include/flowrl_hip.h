@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FRL_ABI_VERSION 5
+#define FRL_ABI_VERSION 6
 #define FRL_MAX_HIDDEN 8 /* hidden Dense layers of the predictor MLP (mlp.py:25) */
 
 /* error codes */
@@ -382,8 +382,11 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
  * continuous_ddpm.py:234-243, cnf.py:155-165) and of every agent that adds its own epsilon / velocity loss on top of
  * add_noise (dql.py:88-92, dac.py:113, qvpo.py:140, sdac.py:91, ...): frl_net_eval_train is frl_net_eval that also keeps
  * act(z) / act'(z) of every layer in the workspace; frl_net_eval_bwd then takes dL/d out and writes dL/d of EVERY
- * parameter leaf (predictor, MLP_0, time_embedding, cond_embedding) and optionally dL/dx.  f32, 256-wide predictor,
- * x_dim <= 24, time_dim + cond_dim <= 192 (DACER: 64 + 128), no LayerNorm; deterministic. */
+ * parameter leaf (predictor, MLP_0, time_embedding, cond_embedding) and optionally dL/dx.  f32, deterministic.  Plain 256-wide
+ * MLP predictors (x_dim <= 24, x_dim + time_dim + cond_dim <= 224) run the fused sweep of the chain VJP with T = 1; every
+ * other predictor the forward evaluates — 512-wide (FQL's actor_bc, fql/fql.py:83-123,189-211), LayerNorm in both orders,
+ * ResidualMLP / Simba (DAC with diffusion.resnet, dac.py:200-207) — runs layer by layer (csrc/net_vjp_layered.hip) and
+ * also needs the LayerNorm / residual-block gradient pointers below. */
 typedef struct FrlEvalBwdBufs {
   const float* x;     /* (B, A)   as the forward call */
   const float* cond;  /* (n_states, C | cond_in_dim) */
@@ -397,6 +400,17 @@ typedef struct FrlEvalBwdBufs {
   float* grad_time_kernel;                /* dL/d time_embedding/kernel (FRL_TEMB_FOURIER) */
   float* grad_cond_kernel[2];             /* dL/d cond_embedding/Dense_{0,1} (desc.cond_embed) */
   float* grad_cond_bias[2];
+  /* desc.layer_norm != 0, MLP backbone: dL/d <predictor>/LayerNorm_i/{scale,bias}, i = 0..L-1 */
+  float* grad_ln_scale[FRL_MAX_HIDDEN];
+  float* grad_ln_bias[FRL_MAX_HIDDEN];
+  /* residual backbones: grad_kernel[0..1] / grad_bias[0..1] = Dense_0 / Dense_1 of the predictor; per block i its Dense_0,
+   * Dense_1 and (when it normalises) LayerNorm_0; Simba's final LayerNorm_0 */
+  float* grad_res_kernel[FRL_MAX_HIDDEN][2];
+  float* grad_res_bias[FRL_MAX_HIDDEN][2];
+  float* grad_res_ln_scale[FRL_MAX_HIDDEN];
+  float* grad_res_ln_bias[FRL_MAX_HIDDEN];
+  float* grad_final_ln_scale;
+  float* grad_final_ln_bias;
 } FrlEvalBwdBufs;
 size_t frl_net_eval_bwd_workspace_bytes(const FrlDesc* desc);
 int frl_net_eval_train(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs* bufs, void* bwd_workspace, size_t workspace_bytes,

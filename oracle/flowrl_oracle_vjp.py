@@ -77,6 +77,116 @@ def _mlp_bwd(p, cache, gout, n_hidden, act_name, has_output, grads):
     return g
 
 
+# ---- LayerNorm / residual predictors (mlp.py:26-29, fql/network.py:26-30, mlp.py:37-98, simba.py:10-63) ----------------
+def _ln_fwd(p, x, eps=1e-6):
+    """flax.linen.LayerNorm as orc.layer_norm computes it, keeping (xhat, rstd) for the backward."""
+    mean = x.mean(axis=-1, keepdims=True)
+    var = np.maximum((x * x).mean(axis=-1, keepdims=True) - mean * mean, 0)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * rstd
+    return xhat * p["scale"] + p["bias"], (xhat, rstd)
+
+
+def _ln_bwd(p, cache, dy, grads):
+    xhat, rstd = cache
+    grads["scale"] = grads.get("scale", 0.0) + (dy * xhat).reshape(-1, xhat.shape[-1]).sum(0)
+    grads["bias"] = grads.get("bias", 0.0) + dy.reshape(-1, xhat.shape[-1]).sum(0)
+    dxh = dy * p["scale"]
+    return rstd * (dxh - dxh.mean(axis=-1, keepdims=True) - xhat * (dxh * xhat).mean(axis=-1, keepdims=True))
+
+
+def _dense_bwd(p, xin, g, grads):
+    grads["kernel"] = grads.get("kernel", 0.0) + xin.reshape(-1, xin.shape[-1]).T @ g.reshape(-1, g.shape[-1])
+    grads["bias"] = grads.get("bias", 0.0) + g.reshape(-1, g.shape[-1]).sum(0)
+    return g @ p["kernel"].T
+
+
+def _pred_fwd(spec, p, x):
+    """The predictor (orc.mlp_apply / residual_mlp_apply / simba_apply) keeping what its backward needs."""
+    act = orc.get_activation(spec.activation)
+    n = len(spec.hidden_dims)
+    tape = []
+    if spec.backbone == "mlp":
+        for i in range(n):
+            z = orc.dense(p[f"Dense_{i}"], x)
+            ent = {"xin": x, "z": z}
+            if spec.layer_norm and not spec.ln_after_act:
+                nz, ent["ln"] = _ln_fwd(p[f"LayerNorm_{i}"], z)
+                ent["n"] = nz
+                x = act(nz)
+            elif spec.layer_norm:
+                x, ent["ln"] = _ln_fwd(p[f"LayerNorm_{i}"], act(z))
+            else:
+                x = act(z)
+            tape.append(ent)
+        tape.append({"xin": x})
+        return orc.dense(p[f"Dense_{n}"], x), tape
+    simba = spec.backbone == "simba"
+    ln = spec.layer_norm or simba
+    bname = "SimbaBlock" if simba else "ResidualLinear"
+    ent0 = {"xin": x}
+    x = orc.dense(p["Dense_0"], x)
+    tape.append(ent0)
+    for i in range(n):
+        b = p[f"{bname}_{i}"]
+        ent = {}
+        y = x
+        if ln:
+            y, ent["ln"] = _ln_fwd(b["LayerNorm_0"], x)
+        ent["y"] = y
+        e = orc.dense(b["Dense_0"], y)
+        ent["e"] = e
+        a = act(e)
+        ent["a"] = a
+        x = x + orc.dense(b["Dense_1"], a)
+        tape.append(ent)
+    ent = {"x": x}
+    if simba:
+        hf, ent["ln"] = _ln_fwd(p["LayerNorm_0"], x)
+    else:
+        hf = act(x)
+    ent["hf"] = hf
+    tape.append(ent)
+    return orc.dense(p["Dense_1"], hf), tape
+
+
+def _pred_bwd(spec, p, tape, gout, grads):
+    n = len(spec.hidden_dims)
+    if spec.backbone == "mlp":
+        g = _dense_bwd(p[f"Dense_{n}"], tape[n]["xin"], gout, grads.setdefault(f"Dense_{n}", {}))
+        for i in reversed(range(n)):
+            ent = tape[i]
+            if spec.layer_norm and not spec.ln_after_act:
+                g = g * act_grad(spec.activation, ent["n"])
+                g = _ln_bwd(p[f"LayerNorm_{i}"], ent["ln"], g, grads.setdefault(f"LayerNorm_{i}", {}))
+            elif spec.layer_norm:
+                g = _ln_bwd(p[f"LayerNorm_{i}"], ent["ln"], g, grads.setdefault(f"LayerNorm_{i}", {}))
+                g = g * act_grad(spec.activation, ent["z"])
+            else:
+                g = g * act_grad(spec.activation, ent["z"])
+            g = _dense_bwd(p[f"Dense_{i}"], ent["xin"], g, grads.setdefault(f"Dense_{i}", {}))
+        return g
+    simba = spec.backbone == "simba"
+    ln = spec.layer_norm or simba
+    bname = "SimbaBlock" if simba else "ResidualLinear"
+    head = tape[n + 1]
+    g = _dense_bwd(p["Dense_1"], head["hf"], gout, grads.setdefault("Dense_1", {}))
+    if simba:
+        g = _ln_bwd(p["LayerNorm_0"], head["ln"], g, grads.setdefault("LayerNorm_0", {}))
+    else:
+        g = g * act_grad(spec.activation, head["x"])
+    for i in reversed(range(n)):
+        b, ent = p[f"{bname}_{i}"], tape[1 + i]
+        gb = grads.setdefault(f"{bname}_{i}", {})
+        ga = _dense_bwd(b["Dense_1"], ent["a"], g, gb.setdefault("Dense_1", {}))
+        ge = ga * act_grad(spec.activation, ent["e"])
+        gy = _dense_bwd(b["Dense_0"], ent["y"], ge, gb.setdefault("Dense_0", {}))
+        if ln:
+            gy = _ln_bwd(b["LayerNorm_0"], ent["ln"], gy, gb.setdefault("LayerNorm_0", {}))
+        g = g + gy
+    return _dense_bwd(p["Dense_0"], tape[0]["xin"], g, grads.setdefault("Dense_0", {}))
+
+
 # ---- predictor with bf16 operands (emulation of csrc/sampler_bf16.hip + csrc/sampler_bwd_bf16.hip) ------------
 # Every Dense contraction takes operands rounded to bf16 and sums exactly: layer inputs and kernels in the forward
 # (orc._predictor_bf16), and in the backward dL/deps and the transposed kernels.  The kernel stashes z_l ONCE, rounded to
@@ -149,6 +259,9 @@ def backbone_fwd(spec: orc.BackboneSpec, params: Dict, x, time, condition):
         return out, c
     parts = [x, tfeat] + ([condition] if condition is not None else [])
     inputs = np.concatenate(parts, axis=-1)
+    if spec.backbone != "mlp" or spec.layer_norm:
+        out, c["pred"] = _pred_fwd(spec, params[spec.predictor_name], inputs)
+        return out, c
     out, c["pred"] = _mlp_fwd(params[spec.predictor_name], inputs, len(spec.hidden_dims), spec.activation, True)
     return out, c
 
@@ -156,6 +269,8 @@ def backbone_fwd(spec: orc.BackboneSpec, params: Dict, x, time, condition):
 def backbone_bwd(spec: orc.BackboneSpec, params: Dict, c, gout, grads: Dict):
     if spec.bf16_operands:
         gin = _pred_bwd_bf16(spec, c["pred"], gout, grads.setdefault(spec.predictor_name, {}))
+    elif spec.backbone != "mlp" or spec.layer_norm:
+        gin = _pred_bwd(spec, params[spec.predictor_name], c["pred"], gout, grads.setdefault(spec.predictor_name, {}))
     else:
         gin = _mlp_bwd(params[spec.predictor_name], c["pred"], gout, len(spec.hidden_dims), spec.activation, True,
                        grads.setdefault(spec.predictor_name, {}))

@@ -33,6 +33,10 @@ RES_CASES = [
 ]
 # the evaluation under jax.grad (frl_net_eval_train / frl_net_eval_bwd): per-sample time, every gradient leaf
 EVAL_VJP_CASE = H.Case("golden_eval_vjp", "cddpm", A=6, S=17, T=20, B=40, temb="learnable_fourier", schedule="cosine", act="silu", seed=111)
+# cfg3's FQL actor_bc under the flow-matching loss (layer-by-layer VJP, csrc/net_vjp_layered.hip): 817 k parameters -> the
+# parameters by seed + SHA-256, every gradient leaf by 4096 seeded entries + its L2 norm
+EVAL_VJP_512 = H.Case("golden_eval_vjp_fql512x4", "cnf", A=8, S=39, T=10, B=64, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None,
+                      clip=False, ln=True, ln_post=True, seed=112)
 VJP_CASE = H.Case("golden_cfg5_vjp", "ddpm", A=3, S=11, T=5, B=40, seed=107)
 CRITIC = dict(name="golden_critic_select", B=12, N=10, S=11, A=3, hidden=(256, 256, 256), act="mish", E=2, seed=108)
 
@@ -54,8 +58,39 @@ CASES = [
 ]
 
 
+def leaf_sample_indices(name: str, size: int, n: int = 4096):
+    import zlib
+    return np.random.default_rng(zlib.crc32(name.encode())).integers(0, size, size=min(n, size))
+
+
+def make_eval_vjp_512():
+    import flowrl_oracle_vjp as ov
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_gpu_vjp import _flatten
+    c = EVAL_VJP_512
+    params, x, cond, _ = H.make_inputs(c)
+    rng = np.random.default_rng(150 + c.seed)
+    t = rng.uniform(0.0, 1.0, size=(c.B, 1)).astype(np.float32)
+    g = rng.standard_normal((c.B, c.A)).astype(np.float32)
+    p64 = orc.cast_tree(params, np.float64)
+    ev_out, cache = ov.backbone_fwd(c.spec, p64, x.astype(np.float64), t.astype(np.float64), cond.astype(np.float64))
+    gref: dict = {}
+    gx = ov.backbone_bwd(c.spec, p64, cache, g.astype(np.float64), gref)
+    keep = dict(x=x, cond=cond, t=t, g=g, out=ev_out, g_x=gx, params_sha256=np.array(params_digest(params)), params_seed=np.array(c.seed))
+    for k, v in _flatten(gref).items():
+        v = np.asarray(v, np.float64).reshape(-1)
+        keep["gs:" + k] = v[leaf_sample_indices(k, v.size)]
+        keep["gn:" + k] = np.array([np.linalg.norm(v), np.abs(v).max()])
+    np.savez_compressed(Path(__file__).resolve().parent / f"{c.name}.npz", **keep)
+    print(c.name, len(_flatten(gref)), "leaves")
+
+
 def main():
     out = Path(__file__).resolve().parent
+    if len(sys.argv) > 1 and sys.argv[1] == "eval512":
+        make_eval_vjp_512()
+        return
+    make_eval_vjp_512()
     for c in CASES:
         params, xT, cond, noise = H.make_inputs(c)
         if c.name == "golden_cfg1_toy2d":

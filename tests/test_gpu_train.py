@@ -191,6 +191,21 @@ EVAL_VJP_CASES = [
     H.Case("evjp-multi-tile", "ddpm", A=3, S=11, T=5, B=20000, seed=66),
     H.Case("evjp-gelu-embed", "cddpm", A=6, S=17, T=20, B=50, temb="learnable_fourier", schedule="linear", cond_embed=True, act="gelu_tanh", seed=67),
     H.Case("evjp-elu", "cnf", A=4, S=9, T=10, B=70, act="elu", clip=False, seed=68),
+    # ---- the layer-by-layer path (csrc/net_vjp_layered.hip): what the fused 256-wide sweep does not carry ----
+    # cfg3's FQL actor_bc under the flow-matching loss (cnf.py:145-170, fql.py:83-123,189-211): 48 -> 512 x 4 -> 8, gelu-tanh, raw t
+    H.Case("evjp-fql-512x4", "cnf", A=8, S=39, T=10, B=256, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None, clip=False, seed=90),
+    H.Case("evjp-fql-512x4-lnpost", "cnf", A=8, S=39, T=10, B=100, hidden=(512, 512, 512, 512), act="gelu_tanh", temb=None, clip=False,
+           ln=True, ln_post=True, seed=91),
+    H.Case("evjp-ln-pre-dql", "ddpm", A=3, S=11, T=5, B=300, ln=True, seed=92),
+    H.Case("evjp-ln-pre-embed-particles", "cddpm", A=17, S=376, T=20, B=5 * 8, particles=8, temb="learnable_fourier", schedule="cosine",
+           cond_embed=True, ln=True, act="silu", seed=93),
+    # DAC with diffusion.resnet (dac.py:200-207): ResidualMLP, 2 blocks, mish + LayerNorm; and without LayerNorm
+    H.Case("evjp-res-dac", "ddpm", A=3, S=11, T=5, B=256, hidden=(256, 256), backbone="residual", ln=True, seed=94),
+    H.Case("evjp-res-noln-ragged", "ddpm", A=6, S=17, T=5, B=70, hidden=(256,), backbone="residual", act="silu", seed=95),
+    # Simba behind DACER's embeddings (backbone_cls: simba), relu
+    H.Case("evjp-simba-dacer", "cddpm", A=17, S=376, T=20, B=4 * 8, particles=8, hidden=(256, 256), backbone="simba", act="relu",
+           temb="learnable_fourier", schedule="cosine", cond_embed=True, seed=96),
+    H.Case("evjp-512-positional", "ddpm", A=3, S=11, T=5, B=5000, hidden=(512, 512), seed=97),      # split over the batch in the dW GEMMs
 ]
 
 
@@ -259,7 +274,10 @@ def test_loss_grads():
     rng = np.random.default_rng(13)
     for case, fn in ((H.Case("lg-ddpm", "ddpm", A=3, S=11, T=5, B=256, seed=71), ddpm_loss),
                      (H.Case("lg-cddpm", "cddpm", A=6, S=17, T=20, B=256, temb="learnable_fourier", schedule="cosine", seed=72), continuous_ddpm_loss),
-                     (H.Case("lg-fm", "cnf", A=8, S=39, T=10, B=256, temb=None, clip=False, hidden=(256, 256), seed=73), flow_matching_loss)):
+                     (H.Case("lg-fm", "cnf", A=8, S=39, T=10, B=256, temb=None, clip=False, hidden=(256, 256), seed=73), flow_matching_loss),
+                     # FQL's own step: the flow-matching loss on the 512 x 4 gelu-tanh actor_bc (fql.py:83-123); DAC-resnet's eps-MSE step
+                     (H.Case("lg-fm-fql512", "cnf", A=8, S=39, T=10, B=256, temb=None, clip=False, hidden=(512, 512, 512, 512), act="gelu_tanh", seed=74), flow_matching_loss),
+                     (H.Case("lg-ddpm-resdac", "ddpm", A=3, S=11, T=5, B=256, hidden=(256, 256), backbone="residual", ln=True, seed=75), ddpm_loss)):
         params, xa, cond, _ = H.make_inputs(case)
         model = H.product_model(case, params)
         c = torch.from_numpy(cond).cuda()
@@ -287,16 +305,21 @@ def test_loss_grads():
 
 
 def test_net_eval_vjp_refusals():
-    """Loud refusals: LayerNorm and non-256 widths have no backward kernel; a missing gradient buffer is FRL_EINVAL."""
+    """Loud refusals: a missing gradient buffer is FRL_EINVAL; the bf16 variant has no single-evaluation VJP."""
+    import ctypes as C
     import torch
-    from flowrl_hip import _lib
-    for case in (H.Case("evjp-ln", "ddpm", A=3, S=11, T=5, B=64, ln=True, seed=80),
-                 H.Case("evjp-512", "cnf", A=8, S=39, T=10, B=64, hidden=(512, 512), temb=None, clip=False, seed=81)):
-        params, x, cond, _ = H.make_inputs(case)
-        model = H.product_model(case, params)
-        t = _t_for(case, np.random.default_rng(1), case.B)
-        with pytest.raises(_lib.FlowRLHipUnsupported):
-            model(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(cond).cuda(), True, model.params, keep_for_vjp=True)
+    from flowrl_hip import _lib, _train
+    case = H.Case("evjp-ln", "ddpm", A=3, S=11, T=5, B=64, ln=True, seed=80)
+    params, x, cond, _ = H.make_inputs(case)
+    model = H.product_model(case, params)
+    t = _t_for(case, np.random.default_rng(1), case.B)
+    out, ctx = model(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(cond).cuda(), True, model.params, keep_for_vjp=True)
+    bufs = _lib.FrlEvalBwdBufs()       # no gradient pointers at all
+    g = torch.zeros((case.B, case.A), device="cuda")
+    bufs.x, bufs.t, bufs.cond, bufs.g_out = ctx.x.data_ptr(), ctx.t.data_ptr(), ctx.cond2d.data_ptr(), g.data_ptr()
+    lib = _lib.load()
+    rc = lib.frl_net_eval_bwd(C.byref(ctx.desc), C.byref(ctx.fparams), C.byref(bufs), ctx.ws.data_ptr(), ctx.ws.numel(), 0)
+    assert rc == _lib.FRL_EINVAL and b"grad_" in lib.frl_last_error()
 
 
 def test_net_eval_vjp_against_committed_golden():
@@ -318,3 +341,33 @@ def test_net_eval_vjp_against_committed_golden():
     for k, v in got.items():
         r = z[k]
         assert np.abs(v - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-30), k
+
+
+def test_net_eval_vjp_fql_512x4_against_committed_golden():
+    """The layer-by-layer VJP on cfg3's FQL actor_bc (48 -> 512 x 4 -> 8, gelu-tanh, raw t, FQL's post-activation LayerNorm)
+    against tests/golden/golden_eval_vjp_fql512x4.npz — every gradient leaf at 4096 seeded entries plus its L2 norm, the
+    parameters regenerated from their seed and checked by SHA-256: no oracle run."""
+    import sys
+    import torch
+    from pathlib import Path
+    gdir = Path(__file__).resolve().parent / "golden"
+    sys.path.insert(0, str(gdir))
+    import make_golden as mg
+    z = np.load(gdir / "golden_eval_vjp_fql512x4.npz")
+    case = mg.EVAL_VJP_512
+    params, _, _, _ = H.make_inputs(case)
+    assert mg.params_digest(params) == str(z["params_sha256"])
+    model = H.product_model(case, params)
+    out, ctx = model(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["t"]).cuda(), torch.from_numpy(z["cond"]).cuda(), True, model.params,
+                     keep_for_vjp=True)
+    grads, gx = model.eval_vjp(ctx, torch.from_numpy(z["g"]).cuda(), want_gx=True)
+    torch.cuda.synchronize()
+    assert H.rel_err(out.cpu().numpy(), z["out"]) <= 1e-5
+    assert np.abs(gx.cpu().numpy() - z["g_x"]).max() <= 1e-5 * np.abs(z["g_x"]).max()
+    got = _flatten(grads)
+    assert {"gs:" + k for k in got} == {k for k in z.files if k.startswith("gs:")}
+    for k, v in got.items():
+        v = v.cpu().numpy().astype(np.float64).reshape(-1)
+        l2, mx = z["gn:" + k]
+        assert abs(np.linalg.norm(v) - l2) <= 1e-5 * l2, k
+        assert np.abs(v[mg.leaf_sample_indices(k, v.size)] - z["gs:" + k]).max() <= 1e-5 * mx, k

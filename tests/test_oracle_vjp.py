@@ -149,3 +149,67 @@ def test_vjp_oracle_reproduces_golden():
     assert set(flat) == set(want)
     for k in want:
         np.testing.assert_allclose(flat[k], want[k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(hidden_dims=[24, 24], layer_norm=True),
+    dict(hidden_dims=[24, 24, 24], layer_norm=True, ln_after_act=True, activation="gelu_tanh", time_embedding=None),
+    dict(hidden_dims=[16, 16], backbone="residual", layer_norm=True),
+    dict(hidden_dims=[16], backbone="residual", activation="silu"),
+    dict(hidden_dims=[16, 16], backbone="simba", activation="relu", time_embedding="learnable_fourier"),
+], ids=["ln-pre", "ln-post-fql", "residual-ln", "residual", "simba"])
+def test_predictor_backward_matches_finite_differences(kw):
+    """The LayerNorm / ResidualMLP / Simba backward of oracle/flowrl_oracle_vjp.py (the checker of the layer-by-layer
+    single-evaluation VJP) against central finite differences of the float64 forward oracle, every leaf and dL/dx."""
+    spec = orc.BackboneSpec(x_dim=3, time_dim=8, **{"activation": "mish", **kw})
+    rng = np.random.default_rng(5)
+    params = orc.cast_tree(orc.make_params(spec, 4, seed=3), np.float64)
+    B = 6
+    x, cond = rng.standard_normal((B, 3)), rng.standard_normal((B, 4))
+    t = rng.uniform(0.05, 0.95, (B, 1)) if spec.time_embedding != "positional" else rng.integers(1, 6, (B, 1)).astype(np.float64)
+    g = rng.standard_normal((B, 3))
+    out, cache = ov.backbone_fwd(spec, params, x, t, cond)
+    assert np.allclose(out, orc.backbone_apply(spec, params, x, t, cond), rtol=1e-12, atol=1e-13)
+    grads: dict = {}
+    gx = ov.backbone_bwd(spec, params, cache, g, grads)
+    loss = lambda p, xx: float(np.sum(g * orc.backbone_apply(spec, p, xx, t, cond)))
+    flat = orc.flatten_tree(params)
+    gflat = orc.flatten_tree(grads)
+    assert set(gflat) == set(flat), (sorted(gflat), sorted(flat))
+    h = 1e-6
+    for name, leaf in flat.items():
+        idxs = [tuple(rng.integers(0, s) for s in leaf.shape) for _ in range(4)]
+        for idx in idxs:
+            pp = {k: v.copy() for k, v in flat.items()}
+            pm = {k: v.copy() for k, v in flat.items()}
+            pp[name][idx] += h
+            pm[name][idx] -= h
+            fd = (loss(orc.unflatten_tree(pp), x) - loss(orc.unflatten_tree(pm), x)) / (2 * h)
+            assert abs(fd - gflat[name][idx]) <= 1e-6 * max(1.0, abs(fd)), (name, idx, fd, gflat[name][idx])
+    for idx in [(0, 0), (3, 2), (5, 1)]:
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += h
+        xm[idx] -= h
+        fd = (loss(params, xp) - loss(params, xm)) / (2 * h)
+        assert abs(fd - gx[idx]) <= 1e-6 * max(1.0, abs(fd)), (idx, fd, gx[idx])
+
+
+def test_oracle_reproduces_fql512_eval_golden():
+    """tests/golden/golden_eval_vjp_fql512x4.npz (made by make_golden.py) is what the float64 oracle gives today."""
+    import sys
+    from pathlib import Path
+    gdir = Path(__file__).resolve().parent / "golden"
+    sys.path.insert(0, str(gdir))
+    import make_golden as mg
+    z = np.load(gdir / "golden_eval_vjp_fql512x4.npz")
+    c = mg.EVAL_VJP_512
+    params, _, _, _ = H.make_inputs(c)
+    assert mg.params_digest(params) == str(z["params_sha256"])
+    p64 = orc.cast_tree(params, np.float64)
+    out, cache = ov.backbone_fwd(c.spec, p64, z["x"].astype(np.float64), z["t"].astype(np.float64), z["cond"].astype(np.float64))
+    grads: dict = {}
+    gx = ov.backbone_bwd(c.spec, p64, cache, z["g"].astype(np.float64), grads)
+    assert np.allclose(out, z["out"], rtol=1e-12, atol=1e-13) and np.allclose(gx, z["g_x"], rtol=1e-12, atol=1e-13)
+    for k, v in orc.flatten_tree(grads).items():
+        v = np.asarray(v).reshape(-1)
+        assert np.allclose(v[mg.leaf_sample_indices(k, v.size)], z["gs:" + k], rtol=1e-11, atol=1e-13), k
