@@ -37,6 +37,17 @@
 
 namespace frl {
 
+// The activation of a register pair.  FRL_RS_SCALAR_ACT (A/B switch, profiles/r03_ab_mish_*.json): two scalar evaluations
+// instead of the packed-f32 form of frl_device.h's act_fn2.
+template <int ACT>
+__device__ __forceinline__ f32x2 rs_act2(f32x2 x) {
+#ifdef FRL_RS_SCALAR_ACT
+  return f32x2{act_fn<ACT>(x[0]), act_fn<ACT>(x[1])};
+#else
+  return act_fn2<ACT>(x);
+#endif
+}
+
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
 __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
   typedef Geo<TR> G;
@@ -263,13 +274,13 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
         // activations are computed two at a time on the even/odd register pair (2m, 2m+1) (an aligned pair, so
         // the packed ops need no moves), one k-step before the first of the two is consumed
         float bop, bn1, bn2 = 0.0f;
-        { const f32x2 y = act_fn2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
+        { const f32x2 y = rs_act2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
           else hload(rsn, std::integral_constant<int, k + RING - 1>{});
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
-            const f32x2 y = act_fn2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            const f32x2 y = rs_act2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
             bn1 = y[0]; bn2 = y[1];
           }
           sfor<NG>([&](auto GI) {
@@ -295,13 +306,13 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
       sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[G::rowr(r) + 4 * ls]; });
       {
         float bop, bn1, bn2 = 0.0f;
-        { const f32x2 y = act_fn2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
+        { const f32x2 y = rs_act2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
             rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsl, voff_l, (k / 4 + RINGL - 1) * 1024);
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
-            const f32x2 y = act_fn2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            const f32x2 y = rs_act2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
             bn1 = y[0]; bn2 = y[1];
           }
           O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
