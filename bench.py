@@ -302,6 +302,7 @@ def cpu_baseline(w, budget_s=15.0):
 def launch_ranks(n: int, argv, stub: bool) -> int:
     """Parent of a multi-GPU run: nothing here touches the GPU (torch.cuda.device_count() only counts devices on this
     image), so the children are ordinary fresh processes — never a re-exec of a process that initialised HIP."""
+    import shutil
     import socket
     import subprocess
     if not stub:
@@ -310,13 +311,18 @@ def launch_ranks(n: int, argv, stub: bool) -> int:
             print(f"bench.py: --gpus {n} asked for, but this box has {have} GPU(s) visible; refusing to run "
                   f"{n} ranks on fewer devices (a scaling number measured that way would be meaningless)", file=sys.stderr, flush=True)
             return 2
+    # Rendezvous of self-launched ranks through a FILE store (a fresh temporary path): probing for a free TCP port and
+    # closing it again would leave a window in which another process takes it.  MASTER_ADDR / MASTER_PORT are still
+    # exported for code that reads them, but the children initialise from FRL_BENCH_INIT.
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    rdv_dir = tempfile.mkdtemp(prefix="frl_bench_rdv_")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), FRL_BENCH_CHILD="1")
+                   MASTER_PORT=str(port), FRL_BENCH_CHILD="1", FRL_BENCH_INIT=f"file://{rdv_dir}/store")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     # rank 0's stdout is drained by a thread; the parent polls EVERY child, so that the early death of any rank ends the
@@ -342,7 +348,9 @@ def launch_ranks(n: int, argv, stub: bool) -> int:
             except subprocess.TimeoutExpired:
                 p.kill()
         print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr, flush=True)
+        shutil.rmtree(rdv_dir, ignore_errors=True)
         return bad[0][1] or 1
+    shutil.rmtree(rdv_dir, ignore_errors=True)
     reader.join(timeout=10)
     sys.stdout.write("".join(chunks))
     sys.stdout.flush()
@@ -353,7 +361,7 @@ def stub_main(args, world: int, rank: int) -> None:
     """CPU stand-in of the rank body (tests/test_host.py): same launcher, same rendezvous, same fence / MAX-over-ranks
     timing and all-gather pattern over gloo, with a trivial step instead of the HIP sampler.  Not a measurement."""
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method=os.environ.get("FRL_BENCH_INIT", "env://"))
     B, A, T = 64, 3, 5
     x = torch.full((B, A), float(rank))
     gathered = torch.empty((world * B, A))
@@ -426,7 +434,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world,
+                                init_method=os.environ.get("FRL_BENCH_INIT", "env://"))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)

@@ -356,14 +356,25 @@ int frl_sampler_prepare(const FrlDesc* desc, const FrlParams* params, const FrlS
   return sampler_prepare_impl(desc, params, sched, workspace, workspace_bytes, hip_stream, PLAN_HOIST | PLAN_W2, true);
 }
 
-int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
-                    void* workspace, size_t workspace_bytes, void* hip_stream) {
-  clear_kernels();
+static int launch_fused_network(const KArgs& a, const CriticTab& ct, int act, hipStream_t stream) {
+  switch (act) {
+    case FRL_ACT_MISH: return launch_sampler_rs_fused_act<FRL_ACT_MISH>(a, ct, stream);
+    case FRL_ACT_SILU: return launch_sampler_rs_fused_act<FRL_ACT_SILU>(a, ct, stream);
+    case FRL_ACT_RELU: return launch_sampler_rs_fused_act<FRL_ACT_RELU>(a, ct, stream);
+    case FRL_ACT_GELU_TANH: return launch_sampler_rs_fused_act<FRL_ACT_GELU_TANH>(a, ct, stream);
+    case FRL_ACT_TANH: return launch_sampler_rs_fused_act<FRL_ACT_TANH>(a, ct, stream);
+    default: return launch_sampler_rs_fused_act<FRL_ACT_ELU>(a, ct, stream);
+  }
+}
+
+// fused: the critic table of frl_sampler_select_fwd (the sampler's launch then scores and selects, x0 optional), or NULL
+static int sampler_run_impl(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
+                            void* workspace, size_t workspace_bytes, void* hip_stream, const CriticTab* fused) {
   int rc = validate_desc(desc);
   if (rc != FRL_OK) return rc;
   if (params == nullptr || bufs == nullptr) { set_error("params / bufs is NULL"); return FRL_EINVAL; }
   Plan pl;
-  plan_from_desc(*desc, pl, PLAN_HOIST | PLAN_W2);
+  plan_from_desc(*desc, pl, fused != nullptr ? PLAN_HOIST : (PLAN_HOIST | PLAN_W2));
   rc = check_ws(pl, workspace, workspace_bytes);
   if (rc != FRL_OK) return rc;
   if (pl.B == 0) {   // empty batch: no chains (the reference returns empty arrays), but the rng still advances
@@ -371,7 +382,7 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
       return launch_rng_chain(bufs->rng_key, desc->rng_impl, pl.mode, pl.T, (uint32_t*)((float*)workspace + pl.off_keys), bufs->rng_out, (hipStream_t)hip_stream);
     return FRL_OK;
   }
-  if (bufs->xT == nullptr || bufs->x0 == nullptr) { set_error("bufs.xT / x0 is NULL"); return FRL_EINVAL; }
+  if (bufs->xT == nullptr || (bufs->x0 == nullptr && fused == nullptr)) { set_error("bufs.xT / x0 is NULL"); return FRL_EINVAL; }
   if ((desc->cond_dim > 0) != (bufs->cond != nullptr)) { set_error("bufs.cond must be non-NULL exactly when cond_dim > 0"); return FRL_EINVAL; }
   const bool needs_noise = (desc->kind != FRL_KIND_CNF) && desc->solver == FRL_SOLVER_DDPM;
   const bool rng = desc->rng_impl != FRL_RNG_NONE;
@@ -447,8 +458,15 @@ int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBu
     return launch_sampler_bf16(*desc, a, (hipStream_t)hip_stream);
   }
   a.wl_raw = params->kernel[pl.L];
+  if (fused != nullptr) return launch_fused_network(a, *fused, desc->act, (hipStream_t)hip_stream);
   if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, (hipStream_t)hip_stream);
   return launch_f32_network(a, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
+}
+
+int frl_sampler_run(const FrlDesc* desc, const FrlParams* params, const FrlFwdBufs* bufs,
+                    void* workspace, size_t workspace_bytes, void* hip_stream) {
+  clear_kernels();
+  return sampler_run_impl(desc, params, bufs, workspace, workspace_bytes, hip_stream, nullptr);
 }
 
 int frl_sampler_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched,
@@ -728,14 +746,14 @@ int frl_sampler_bwd(const FrlDesc* desc, const FrlParams* params, const FrlSched
 }
 
 // ---- critic scoring + best-of-N selection ------------------------------------------------------
-static int critic_plan(const FrlCriticDesc* c, FrlDesc& d, Plan& pl, bool& hoist) {
+static int critic_plan(const FrlCriticDesc* c, FrlDesc& d, Plan& pl, bool& hoist, bool force_hoist = false) {
   if (c == nullptr) { set_error("critic desc is NULL"); return FRL_EINVAL; }
   if (c->abi_version != FRL_ABI_VERSION) { set_error("critic desc.abi_version %d != library %d", c->abi_version, FRL_ABI_VERSION); return FRL_EINVAL; }
   if (c->ensemble < 1 || c->ensemble > 16) { set_error("ensemble %d outside [1, 16]", c->ensemble); return FRL_EINVAL; }
   if (c->act_dim < 1 || c->obs_dim < 0) { set_error("act_dim %d / obs_dim %d invalid", c->act_dim, c->obs_dim); return FRL_EINVAL; }
   // The observation rows of Dense_0 are the same for every candidate of a state: with several candidates per state (or
   // an observation wider than the kernel's condition operand budget) they are hoisted into a per-state accumulator init.
-  hoist = c->obs_dim > 0 && (c->particles > 1 || c->obs_dim > 32);
+  hoist = c->obs_dim > 0 && (c->particles > 1 || c->obs_dim > 32 || force_hoist);
   memset(&d, 0, sizeof(d));
   d.abi_version = FRL_ABI_VERSION;
   d.kind = FRL_KIND_CNF; d.solver = FRL_SOLVER_EULER; d.steps = 1;      // carrier only: the mode is overridden below
@@ -827,6 +845,119 @@ int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, 
   }
   return launch_critic_select(qm, E, desc->n_states, desc->particles, pl.A, bufs->actions, bufs->gumbel, bufs->inv_temperature,
                               bufs->q, bufs->best_idx, bufs->best_action, stream);
+}
+
+// ---- sampler + critic scoring + selection in one launch ----------------------------------------------------------------
+struct SelectPlan {
+  Plan pl, cpl;             // sampler (32-chain geometry, condition rows hoisted where the plan says) / one critic member
+  FrlDesc cd;
+  bool obs;
+  size_t off_members, off_zs, off_tab, total_floats;
+};
+
+static int select_plan(const FrlDesc* desc, const FrlCriticDesc* cdesc, SelectPlan& sp) {
+  int rc = validate_desc(desc);
+  if (rc != FRL_OK) return rc;
+  if (cdesc == nullptr) { set_error("critic desc is NULL"); return FRL_EINVAL; }
+  if (desc->dtype != FRL_DTYPE_F32 || desc->backbone != FRL_BACKBONE_MLP || desc->layer_norm || desc->rng_impl != FRL_RNG_NONE) {
+    set_error("fused sample+select: f32 MLP sampler without LayerNorm and with caller-supplied noise only"); return FRL_EUNSUPPORTED; }
+  if (desc->n_hidden < 2) { set_error("fused sample+select: the sampler needs >= 2 hidden layers"); return FRL_EUNSUPPORTED; }
+  plan_from_desc(*desc, sp.pl, PLAN_HOIST);
+  const Plan& pl = sp.pl;
+  if (pl.H != 256 || pl.TR != 32) { set_error("fused sample+select: 256-wide sampler only (got %d)", pl.H); return FRL_EUNSUPPORTED; }
+  if (!((pl.AR <= 4 && pl.CK <= 12) || (pl.AR <= 12 && pl.CK == 0))) {
+    set_error("fused sample+select: x_dim %d with %d in-kernel condition rows has no build (x_dim <= 8 with cond_dim <= 24, or a hoisted condition: particles >= 4 and cond_dim >= 32)", pl.A, pl.C);
+    return FRL_EUNSUPPORTED; }
+  if (cdesc->n_states != desc->n_states || cdesc->particles != desc->particles || cdesc->act_dim != desc->x_dim) {
+    set_error("fused sample+select: critic n_states / particles / act_dim (%lld, %d, %d) differ from the sampler's (%lld, %d, %d)",
+              (long long)cdesc->n_states, cdesc->particles, cdesc->act_dim, (long long)desc->n_states, desc->particles, desc->x_dim); return FRL_EINVAL; }
+  const int N = desc->particles;
+  if (!((N <= 32 && (N & (N - 1)) == 0) || N % 32 == 0)) { set_error("fused sample+select: particles %d (a power of two <= 32 or a multiple of 32)", N); return FRL_EUNSUPPORTED; }
+  if (cdesc->ensemble < 1 || cdesc->ensemble > FUSE_MAX_E) { set_error("fused sample+select: ensemble %d outside [1, %d]", cdesc->ensemble, FUSE_MAX_E); return FRL_EUNSUPPORTED; }
+  if (cdesc->n_hidden < 2 || cdesc->n_hidden > FUSE_MAX_L) { set_error("fused sample+select: critic hidden layers %d outside [2, %d]", cdesc->n_hidden, FUSE_MAX_L); return FRL_EUNSUPPORTED; }
+  for (int l = 0; l < cdesc->n_hidden; ++l)
+    if (cdesc->hidden[l] != 256) { set_error("fused sample+select: critic hidden widths must all be 256 (hidden[%d] = %d)", l, cdesc->hidden[l]); return FRL_EUNSUPPORTED; }
+  if (cdesc->act != desc->act && cdesc->act != FRL_ACT_RELU) { set_error("fused sample+select: critic activation %d is neither the sampler's (%d) nor relu", cdesc->act, desc->act); return FRL_EUNSUPPORTED; }
+  bool hoist;
+  rc = critic_plan(cdesc, sp.cd, sp.cpl, hoist, true);
+  if (rc != FRL_OK) return rc;
+  if (sp.cpl.TR != 32 || sp.cpl.XR != pl.XR || sp.cpl.AR != pl.AR || sp.cpl.C != 0) { set_error("fused sample+select: critic plan does not match the sampler's geometry"); return FRL_EINVAL; }
+  sp.obs = hoist;
+  const size_t E = (size_t)cdesc->ensemble;
+  sp.off_members = (pl.total_floats + 63) & ~(size_t)63;
+  sp.off_zs = sp.off_members + E * ((sp.cpl.total_floats + 63) & ~(size_t)63);
+  sp.off_tab = sp.off_zs + (sp.obs ? ((E * (size_t)desc->n_states * 256 + 63) & ~(size_t)63) : 0);
+  sp.total_floats = sp.off_tab + ((sizeof(CriticPtrs) / sizeof(float) + 63) & ~(size_t)63);
+  return FRL_OK;
+}
+
+size_t frl_sampler_select_workspace_bytes(const FrlDesc* desc, const FrlCriticDesc* cdesc) {
+  SelectPlan sp;
+  if (select_plan(desc, cdesc, sp) != FRL_OK) return 0;
+  return sp.total_floats * sizeof(float);
+}
+
+int frl_sampler_select_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* fwd,
+                           const FrlCriticDesc* cdesc, const FrlCriticParams* cparams, const FrlSelectBufs* sel,
+                           void* workspace, size_t workspace_bytes, void* hip_stream) {
+  clear_kernels();
+  SelectPlan sp;
+  int rc = select_plan(desc, cdesc, sp);
+  if (rc != FRL_OK) return rc;
+  if (params == nullptr || fwd == nullptr || cparams == nullptr || sel == nullptr) { set_error("params / fwd / cparams / sel is NULL"); return FRL_EINVAL; }
+  if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) { set_error("workspace must be non-NULL and 256-byte aligned"); return FRL_EWORKSPACE; }
+  if (workspace_bytes < sp.total_floats * sizeof(float)) { set_error("workspace %zu B < required %zu B (frl_sampler_select_workspace_bytes)", workspace_bytes, sp.total_floats * sizeof(float)); return FRL_EWORKSPACE; }
+  if (sp.pl.B == 0) return FRL_OK;
+  if (desc->want_history) { set_error("fused sample+select: want_history is not carried (use frl_sampler_fwd + frl_critic_select)"); return FRL_EUNSUPPORTED; }
+  if ((cdesc->obs_dim > 0) != (sel->obs != nullptr)) { set_error("sel.obs must be non-NULL exactly when obs_dim > 0"); return FRL_EINVAL; }
+  if (sel->best_action == nullptr && sel->best_idx == nullptr && sel->q == nullptr) { set_error("no output requested (q / best_idx / best_action all NULL)"); return FRL_EINVAL; }
+  for (int l = 0; l <= cdesc->n_hidden; ++l)
+    if (cparams->kernel[l] == nullptr || cparams->bias[l] == nullptr) { set_error("cparams.kernel/bias[%d] is NULL", l); return FRL_EINVAL; }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  float* ws = (float*)workspace;
+  const Plan& cpl = sp.cpl;
+  const int E = cdesc->ensemble, L = cpl.L, H = 256, K0 = cdesc->obs_dim + cpl.A;
+  const size_t mstride = (cpl.total_floats + 63) & ~(size_t)63;
+  CriticPtrs cp;
+  memset(&cp, 0, sizeof(cp));
+  for (int e = 0; e < E; ++e) {
+    // member e of every stacked leaf (Ensemblize: nn.vmap with variable_axes params = 0, critic.py:154-172)
+    PArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    for (int l = 0; l <= L; ++l) {
+      const size_t rows = (l == 0) ? (size_t)K0 : (size_t)H, cols = (l == L) ? 1 : (size_t)H;
+      pa.p.kernel[l] = cparams->kernel[l] + (size_t)e * rows * cols;
+      pa.p.bias[l] = cparams->bias[l] + (size_t)e * cols;
+    }
+    float* wse = ws + sp.off_members + (size_t)e * mstride;
+    pa.ws = wse; pa.plan = cpl; pa.kind = FRL_KIND_CNF; pa.time_embed = FRL_TEMB_NONE;
+    rc = launch_prepare(pa, stream);
+    if (rc != FRL_OK) return rc;
+    const float** m = cp.p + e * CT_STRIDE;
+    m[CT_W0P] = wse + cpl.off_w0p; m[CT_WLQ] = wse + cpl.off_wlq; m[CT_TB] = wse + cpl.off_tb; m[CT_BLP] = wse + cpl.off_blp;
+    if (sp.obs) {
+      float* zse = ws + sp.off_zs + (size_t)e * desc->n_states * H;
+      rc = launch_state_bias(sel->obs, desc->n_states, cdesc->obs_dim, H, pa.p.kernel[0], nullptr, zse, stream);   // bias_0 is in tb
+      if (rc != FRL_OK) return rc;
+      m[CT_ZS] = zse;
+    }
+    for (int l = 1; l < L; ++l) { m[CT_WH + l - 1] = pa.p.kernel[l]; m[CT_BH + l - 1] = pa.p.bias[l]; }
+  }
+  const float** tab = (const float**)(ws + sp.off_tab);
+  rc = launch_critic_tab(cp, tab, stream);
+  if (rc != FRL_OK) return rc;
+  CriticTab ct;
+  memset(&ct, 0, sizeof(ct));
+  ct.E = E; ct.L = L; ct.relu = (cdesc->act == FRL_ACT_RELU && desc->act != FRL_ACT_RELU) ? 1 : 0;
+  const int N = desc->particles;
+  ct.seg = N <= 32 ? N : 32; ct.group = N <= 32 ? 1 : N / 32;
+  ct.w0p_bytes = (int)(cpl.w0p_rows * cpl.H * sizeof(float));
+  ct.ptrs = tab;
+  if (sel->gumbel != nullptr) { ct.gumbel = sel->gumbel; ct.inv_temperature = sel->inv_temperature; }
+  ct.q = sel->q; ct.best_idx = sel->best_idx; ct.best_action = sel->best_action;
+  rc = sampler_prepare_impl(desc, params, sched, workspace, sp.pl.total_floats * sizeof(float), hip_stream, PLAN_HOIST);
+  if (rc != FRL_OK) return rc;
+  return sampler_run_impl(desc, params, fwd, workspace, sp.pl.total_floats * sizeof(float), hip_stream, &ct);
 }
 
 int frl_random_split(const uint32_t* key, int32_t impl, int32_t num, uint32_t* out, void* hip_stream) {

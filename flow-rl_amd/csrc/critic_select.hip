@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) frl_critic_select_kernel(const float* __r
       float v = qm[c];
       for (int e = 1; e < E; ++e) v = fminf(v, qm[(size_t)e * B + c]);     // qs.min(axis=0)
       if (q != nullptr) q[c] = v;
-      const float key = (gumbel != nullptr) ? v * inv_temp + gumbel[c] : v; // categorical == argmax(logits + Gumbel)
+      const float key = (gumbel != nullptr) ? fmaf(v, inv_temp, gumbel[c]) : v; // categorical == argmax(logits + Gumbel)
       if (bi == 0x7fffffff || key > best) { best = key; bi = p; }           // strict >: the first maximum wins
     }
     // wave reduction: larger key wins, equal keys -> smaller index
@@ -39,6 +39,19 @@ __global__ void __launch_bounds__(256) frl_critic_select_kernel(const float* __r
       for (int a = lane; a < A; a += 64) best_action[s * A + a] = src[a];
     }
   }
+}
+
+// the fused sampler's per-member pointer table (frl_internal.h CriticTab.ptrs), from kernel arguments to device memory
+__global__ void __launch_bounds__(64) frl_critic_tab_kernel(const CriticPtrs v, const float** __restrict__ dst) {
+  const int i = threadIdx.x;
+  if (i < FUSE_MAX_E * CT_STRIDE) dst[i] = v.p[i];
+}
+
+int launch_critic_tab(const CriticPtrs& v, const float** dst, hipStream_t stream) {
+  hipLaunchKernelGGL(frl_critic_tab_kernel, dim3(1), dim3(64), 0, stream, v, dst);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("critic table launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  return FRL_OK;
 }
 
 int launch_critic_select(const float* q_members, int E, long long n_states, int particles, int A, const float* actions,

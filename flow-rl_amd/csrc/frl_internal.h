@@ -196,6 +196,33 @@ struct KArgs {
                                           // every layer and step in the chain VJP's stash layout (BArgs.hd / ad), else NULL
 };
 
+// Critic scoring + best-of-N selection FUSED into the sampler launch (csrc/sampler_rs.hip, EXT 3 builds): after the last
+// step a tile's x0 sits in the chain-state registers in exactly the B-operand layout Dense_0 wants, so the E critic members
+// (Ensemblize(ScalarCritic(MLP)), critic.py:154-194) are evaluated on the tile in place, the minimum over the ensemble is
+// kept in a register, and the argmax / Gumbel-max over a state's particles runs across lanes (and, for >= 32 particles,
+// across the consecutive tiles of the state, which one wave owns).  Only (n_states, A) actions leave the chip.
+constexpr int FUSE_MAX_E = 4, FUSE_MAX_L = 4;
+// Per-member pointer table in device memory (written by frl_critic_tab_kernel, csrc/critic_select.hip): the kernel indexes
+// it with the running member / layer number, which a kernel-argument array would pay for with a scratch copy.
+//   [CT_W0P] packed action rows of Dense_0 (Plan.off_w0p of the critic plan)   [CT_WLQ] packed head   [CT_TB] [H] bias_0
+//   [CT_BLP] [32] padded head bias   [CT_ZS] [n_states][H] observation rows of Dense_0, once per state, or NULL (obs_dim = 0)
+//   [CT_WH + l - 1] / [CT_BH + l - 1] hidden kernel / bias of layer l
+enum { CT_W0P = 0, CT_WLQ = 1, CT_TB = 2, CT_BLP = 3, CT_ZS = 4, CT_WH = 5, CT_BH = CT_WH + FUSE_MAX_L - 1, CT_STRIDE = 12 };
+static_assert(CT_BH + FUSE_MAX_L - 1 <= CT_STRIDE, "critic pointer table");
+struct CriticPtrs { const float* p[FUSE_MAX_E * CT_STRIDE]; };
+struct CriticTab {
+  int E, L;                 // ensemble members, hidden layers of the critic backbone (256 wide)
+  int relu;                 // 1: the critic's activation is relu; 0: the sampler's own (compiled) activation
+  int seg, group;           // particles per state inside a tile (power of two <= 32) / consecutive tiles per state
+  float inv_temperature;    // with gumbel: argmax(q * inv_temperature + gumbel)
+  int w0p_bytes;
+  const float* const* ptrs; // device copy of CriticPtrs: member e at [e CT_STRIDE + CT_*]
+  const float* gumbel;      // (n_states, particles) or NULL
+  float* q;                 // (n_states, particles) min over the ensemble, or NULL
+  int32_t* best_idx;        // (n_states,) or NULL
+  float* best_action;       // (n_states, A)
+};
+
 // Residual-backbone part of the sampler's arguments (csrc/sampler_res.hip): block i = Dense (H, 4H) -> act -> Dense (4H, H)
 // around a residual, optionally behind a LayerNorm; kernels read in place.
 struct ResArgs {
@@ -430,6 +457,7 @@ void note_kernel(const char* fmt, ...);
 // launchers implemented in the .hip files
 int launch_prepare(const PArgs& a, hipStream_t stream);
 template <int ACT> int launch_sampler_rs_act(const KArgs& a, hipStream_t stream);  // register-streamed variant, one TU per activation
+template <int ACT> int launch_sampler_rs_fused_act(const KArgs& a, const CriticTab& ct, hipStream_t stream);  // + critic scoring / selection (EXT 3)
 template <int ACT> int launch_sampler_res_act(const KArgs& a, const ResArgs& ra, hipStream_t stream);  // residual backbones (csrc/sampler_res.hip)
 template <int ACT> int launch_sampler_lat_act(const KArgs& a, int tile_rows, hipStream_t stream); // latency variant (4 waves per tile), one TU per activation
 // CU count of the current device (cached per thread and device)
@@ -468,6 +496,7 @@ int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim,
                        const float* w1, const float* b1, float* cfeat, hipStream_t stream);
 int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, const float* w, const float* b, float* zs,
                       hipStream_t stream);
+int launch_critic_tab(const CriticPtrs& v, const float** dst, hipStream_t stream);
 int launch_critic_select(const float* q_members, int E, long long n_states, int particles, int A, const float* actions,
                          const float* gumbel, float inv_temperature, float* q, int32_t* best_idx, float* best_action,
                          hipStream_t stream);

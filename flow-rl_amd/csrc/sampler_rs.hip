@@ -48,8 +48,10 @@ __device__ __forceinline__ f32x2 rs_act2(f32x2 x) {
 #endif
 }
 
+// EXT: 0 plain, 1 rarer solvers / evaluation / hoisted condition rows, 2 = 1 + in-kernel draws + LayerNorm,
+//      3 = 1 + critic scoring and best-of-N selection on the finished tile (CriticTab, frl_internal.h)
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
-__device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
+__device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab& ct) {
   typedef Geo<TR> G;
   typedef typename G::acc_t acc_t;
   constexpr int KS = G::KS, NR = G::NR, RING = G::RING;
@@ -80,9 +82,27 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
   for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
   float* s_ln = s_coef + a.NE * COEF_STRIDE;          // EXT 2, LayerNorm backbones only: [L][2][H] scale | bias rows
-  if constexpr (EXT >= 2) {
+  if constexpr (EXT == 2) {
     if (a.ws_ln != nullptr)
       for (int idx = tid; idx < a.L * 2 * H; idx += blockDim.x) s_ln[idx] = a.ws_ln[idx];
+  }
+  // EXT 3: the critic members' biases behind the sampler's tables: [E][H] bias_0 | [E][Lc-1][H] hidden | [E][32] padded head
+  float* s_ctb = s_ln;
+  float* s_cbh = s_ctb;
+  float* s_cbl = s_ctb;
+  if constexpr (EXT == 3) {
+    static_assert(TR == 32, "fused critic: 32-chain tiles");
+    s_cbh = s_ctb + ct.E * H;
+    s_cbl = s_cbh + ct.E * (ct.L - 1) * H;
+    for (int e = 0; e < ct.E; ++e) {
+      const float* tp = ct.ptrs[e * CT_STRIDE + CT_TB];
+      for (int idx = tid; idx < H; idx += blockDim.x) s_ctb[e * H + idx] = tp[idx];
+      for (int l = 1; l < ct.L; ++l) {
+        const float* bp = ct.ptrs[e * CT_STRIDE + CT_BH + l - 1];
+        for (int idx = tid; idx < H; idx += blockDim.x) s_cbh[(e * (ct.L - 1) + l - 1) * H + idx] = bp[idx];
+      }
+      if (tid < LAST_PAD) s_cbl[e * LAST_PAD + tid] = ct.ptrs[e * CT_STRIDE + CT_BLP][tid];
+    }
   }
   __syncthreads();
 
@@ -165,13 +185,12 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
   // the descriptor bounds-checks) so that the vmcnt bookkeeping stays exact across the uniform `live` branches.
   constexpr int N0 = NRX + CKMAX;       // compile-time k-step slots; slot n is live iff live(n)
   f32x4 r0[RING][NG];
-  auto live = [&](int n) { return n < NRX ? n < a.AR : (n - NRX) < a.CK; };
-  auto l0load = [&](auto NI) {
+  auto l0load = [&](__amdgpu_buffer_rsrc_t rs, auto NI) {
     constexpr int n = decltype(NI)::value;
     sfor<NG>([&](auto GI) {
       constexpr int g = decltype(GI)::value;
-      if constexpr (n < NRX) r0[n % RING][g] = ldw(rs0, voff_x + g * (GW * 4), G::rowr(n) * ROWB);
-      else r0[n % RING][g] = ldw(rs0, voff_c + g * (GW * 4), (a.XR + KS * (n - NRX)) * ROWB);
+      if constexpr (n < NRX) r0[n % RING][g] = ldw(rs, voff_x + g * (GW * 4), G::rowr(n) * ROWB);
+      else r0[n % RING][g] = ldw(rs, voff_c + g * (GW * 4), (a.XR + KS * (n - NRX)) * ROWB);
     });
   };
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.L > 1 ? a.wh[0] : a.ws_w0p), 0, H * ROWB, 0x00020000);
@@ -181,10 +200,22 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
 
   // Weight operands never depend on the data, so the first ring entries of Dense_0 and of the first hidden layer
   // are fetched one step ahead (before the previous step's Dense_L) and stay valid across steps and tiles.
-  sfor<RING - 1>([&](auto NI) { l0load(NI); });
+  sfor<RING - 1>([&](auto NI) { l0load(rs0, NI); });
   if (a.L > 1) sfor<RING - 1>([&](auto KI) { hload(rs1, KI); });
 
-  for (int wt = blockIdx.x * nw + wave; wt < n_wt; wt += gridDim.x * nw) {
+  // EXT 3: a state's particles fill `group` CONSECUTIVE tiles, which one wave takes in turn (the running maximum over
+  // the state's candidates stays in its registers); every other build: one tile per turn
+  const int n_tg = (EXT == 3) ? ct.group : 1;
+  const int n_grp = (n_wt + n_tg - 1) / n_tg;
+  float gkey = 0.0f;          // EXT 3: best selection key of the state so far, its particle index and its action
+  int gbi = 0;
+  float gx[EXT == 3 ? NRX : 1];
+  sfor<(EXT == 3 ? NRX : 1)>([&](auto RI) { gx[decltype(RI)::value] = 0.0f; });
+
+  for (int grp = blockIdx.x * nw + wave; grp < n_grp; grp += gridDim.x * nw)
+  for (int tg = 0; tg < n_tg; ++tg) {
+    const int wt = grp * n_tg + tg;
+    if (wt >= n_wt) break;
     const long long chain = (long long)wt * TR + li;
     const bool valid = chain < a.B;
     const long long state = (a.particles == 1) ? chain : chain / a.particles;
@@ -206,9 +237,29 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
     float aux[EXT ? NRX : 1];
     sfor<(EXT ? NRX : 1)>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
 
-    for (int j = 0; j < a.NE; ++j) {   // one iteration per network evaluation (= per sampler step, except dpm2: two)
+    // one iteration per network evaluation (= per sampler step, except dpm2: two); EXT 3: then one per critic member on
+    // the finished x0 (same Dense_0 / hidden / head code, the member's tables; the operand prefetches chain through)
+    const int n_ev = a.NE + (EXT == 3 ? ct.E : 0);
+    float qmin = 0.0f;
+    for (int j = 0; j < n_ev; ++j) {
+      const bool crit = (EXT == 3) && j >= a.NE;            // this evaluation is critic member ce
+      const int ce = crit ? j - a.NE : 0;
+      const int jn = (j + 1 < n_ev) ? j + 1 : 0;            // the evaluation whose first operands are prefetched
+      const bool critn = (EXT == 3) && jn >= a.NE;
+      const int Lj = crit ? ct.L : a.L;
+      const int jc = crit ? 0 : j;                          // row of the coefficient / time-bias tables
+      const __amdgpu_buffer_rsrc_t rs0c = crit ? __builtin_amdgcn_make_buffer_rsrc((void*)ct.ptrs[ce * CT_STRIDE + CT_W0P], 0, ct.w0p_bytes, 0x00020000) : rs0;
+      const __amdgpu_buffer_rsrc_t rs0n = critn ? __builtin_amdgcn_make_buffer_rsrc((void*)ct.ptrs[(jn - a.NE) * CT_STRIDE + CT_W0P], 0, ct.w0p_bytes, 0x00020000) : rs0;
+      const __amdgpu_buffer_rsrc_t rslc = crit ? __builtin_amdgcn_make_buffer_rsrc((void*)ct.ptrs[ce * CT_STRIDE + CT_WLQ], 0, NK * 64 * 4, 0x00020000) : rsl;
+      auto live = [&](int n) { return n < NRX ? n < a.AR : (!crit && (n - NRX) < a.CK); };
+      // the critic's activation: the sampler's compiled one, or relu (QVPO / DACER critics beside a mish actor)
+      auto act2 = [&](f32x2 x) __attribute__((always_inline)) {
+        f32x2 y = rs_act2<ACT>(x);
+        if constexpr (EXT == 3 && ACT != FRL_ACT_RELU) { if (crit && ct.relu) y = f32x2{act_fn<FRL_ACT_RELU>(x[0]), act_fn<FRL_ACT_RELU>(x[1])}; }
+        return y;
+      };
       float zr[NRX];
-      if constexpr (EXT >= 2) {
+      if constexpr (EXT == 2) {
         // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai] (frl_rng.h), drawn while no accumulator is live
         if (a.rng_impl != FRL_RNG_NONE) {
           const bool used = s_coef[j * COEF_STRIDE + 5] != 0.0f;   // c5 = 0: the last iteration multiplies its draw by 0 (ddpm.py:206)
@@ -220,12 +271,14 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
         }
       }
       // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
-      bias_init(P, s_tb + j * H);
+      bias_init(P, crit ? s_ctb + ce * H : s_tb + j * H);
       if constexpr (EXT) {
-        if (a.state_bias != nullptr) {
+        const float* sbias = a.state_bias;
+        if constexpr (EXT == 3) { if (crit) sbias = ct.ptrs[ce * CT_STRIDE + CT_ZS]; }
+        if (sbias != nullptr) {
           // hoisted per-state slice of Dense_0 (the condition / observation rows, computed once per state by
           // frl_state_bias_kernel): every lane adds the row of ITS state; chains of one state share the cache lines
-          const float* zrow = a.state_bias + (valid ? state : 0) * H;
+          const float* zrow = sbias + (valid ? state : 0) * H;
           sfor<NG>([&](auto GI) {
             constexpr int g = decltype(GI)::value;
             sfor<NR>([&](auto RI) {
@@ -238,7 +291,7 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
       }
       sfor<N0>([&](auto NI) {
         constexpr int n = decltype(NI)::value;
-        if constexpr (n + RING - 1 < N0) l0load(std::integral_constant<int, n + RING - 1>{});
+        if constexpr (n + RING - 1 < N0) l0load(rs0c, std::integral_constant<int, n + RING - 1>{});
         if (live(n)) {
           float bop;
           if constexpr (n < NRX) bop = xs[n]; else bop = cb[n - NRX];
@@ -251,36 +304,47 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
       });
 
       // noise for this step and the first Dense_L operands: issued now, consumed after the hidden layers
-      if (EXT < 2 || a.rng_impl == FRL_RNG_NONE) {
+      if (EXT != 2 || a.rng_impl == FRL_RNG_NONE) {
         sfor<NRX>([&](auto RI) {
           constexpr int r = decltype(RI)::value;
           const int ai = G::rowr(r) + 4 * ls;
-          zr[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+          zr[r] = (a.noise != nullptr && !crit && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         });
       }
-      if constexpr (EXT >= 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
+      if constexpr (EXT == 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
       constexpr int NLD = NK / 4;    // Dense_L: 16-byte loads, load q covers k-steps 4q .. 4q+3
       f32x4 rl[RINGL];
-      sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rsl, voff_l, q * 1024); });
+      sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rslc, voff_l, q * 1024); });
 
       // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P) ; P <- Q ----------------------------
-      for (int l = 1; l < a.L; ++l) {
+      for (int l = 1; l < Lj; ++l) {
         // operands of this layer's first RING-1 k-steps are already in flight; the tail prefetches the next
-        // layer's — after the last hidden layer that is the FIRST hidden layer again (next step / next tile)
-        const float* wn = pick_ptr_rs(a.wh, (l + 1 < a.L) ? l : 0);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr_rs(a.wh, l - 1), 0, H * ROWB, 0x00020000);
+        // layer's — after the last hidden layer that is the FIRST hidden layer of the next evaluation (next step /
+        // critic member / tile)
+        const float* wc = pick_ptr_rs(a.wh, l - 1);
+        const float* wn = pick_ptr_rs(a.wh, (l + 1 < Lj) ? l : 0);
+        const float* sb = s_bh + (l - 1) * H;
+        if constexpr (EXT == 3) {
+          if (crit) {
+            wc = ct.ptrs[ce * CT_STRIDE + CT_WH + l - 1];
+            sb = s_cbh + (ce * (ct.L - 1) + l - 1) * H;
+            if (l + 1 < Lj) wn = ct.ptrs[ce * CT_STRIDE + CT_WH + l];
+          }
+          if (l + 1 >= Lj) wn = critn ? ct.ptrs[(jn - a.NE) * CT_STRIDE + CT_WH] : a.wh[0];
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wc, 0, H * ROWB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)wn, 0, H * ROWB, 0x00020000);
-        bias_init(Q, s_bh + (l - 1) * H);
+        bias_init(Q, sb);
         // activations are computed two at a time on the even/odd register pair (2m, 2m+1) (an aligned pair, so
         // the packed ops need no moves), one k-step before the first of the two is consumed
         float bop, bn1, bn2 = 0.0f;
-        { const f32x2 y = rs_act2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
+        { const f32x2 y = act2(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
           else hload(rsn, std::integral_constant<int, k + RING - 1>{});
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
-            const f32x2 y = rs_act2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            const f32x2 y = act2(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
             bn1 = y[0]; bn2 = y[1];
           }
           sfor<NG>([&](auto GI) {
@@ -295,24 +359,24 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
           bop = bn1; bn1 = bn2;
         });
         sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; P[b] = Q[b]; });
-        if constexpr (EXT >= 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
+        if constexpr (EXT == 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
       }
 
       // next step's (or next tile's) first Dense_0 operands: in flight under Dense_L and the epilogue
-      sfor<RING - 1>([&](auto NI) { l0load(NI); });
+      sfor<RING - 1>([&](auto NI) { l0load(rs0n, NI); });
 
       // ---------------- Dense_L : O = b_L + W_L^T act(P), padded to TR rows --------------------------
       acc_t O;
-      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[G::rowr(r) + 4 * ls]; });
+      sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = (crit ? s_cbl + ce * LAST_PAD : s_bl)[G::rowr(r) + 4 * ls]; });
       {
         float bop, bn1, bn2 = 0.0f;
-        { const f32x2 y = rs_act2<ACT>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
+        { const f32x2 y = act2(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
-            rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rsl, voff_l, (k / 4 + RINGL - 1) * 1024);
+            rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rslc, voff_l, (k / 4 + RINGL - 1) * 1024);
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
-            const f32x2 y = rs_act2<ACT>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            const f32x2 y = act2(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
             bn1 = y[0]; bn2 = y[1];
           }
           O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
@@ -321,15 +385,19 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
       }
 
       // ---------------- epilogue: one reverse-diffusion / Euler step ---------------------------------
-      const float c0 = s_coef[j * COEF_STRIDE + 0], c1 = s_coef[j * COEF_STRIDE + 1];
-      const float c2 = s_coef[j * COEF_STRIDE + 2], c3 = s_coef[j * COEF_STRIDE + 3];
-      const float c4 = s_coef[j * COEF_STRIDE + 4], c5 = s_coef[j * COEF_STRIDE + 5];
+      if constexpr (EXT == 3) {
+        // critic member ce: its scalar output is row 0 of the head = register 0 of lanes 0 .. 31; qs.min(axis=0), dql.py:155
+        if (crit) { qmin = (ce == 0) ? O[0] : fminf(qmin, O[0]); continue; }
+      }
+      const float c0 = s_coef[jc * COEF_STRIDE + 0], c1 = s_coef[jc * COEF_STRIDE + 1];
+      const float c2 = s_coef[jc * COEF_STRIDE + 2], c3 = s_coef[jc * COEF_STRIDE + 3];
+      const float c4 = s_coef[jc * COEF_STRIDE + 4], c5 = s_coef[jc * COEF_STRIDE + 5];
       sfor<NRX>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
         const int ai = G::rowr(r) + 4 * ls;
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
-        const float c6 = EXT ? s_coef[j * COEF_STRIDE + 6] : 0.0f;   // dpm2: 1 on the second evaluation of a step
+        const float c6 = EXT ? s_coef[jc * COEF_STRIDE + 6] : 0.0f;   // dpm2: 1 on the second evaluation of a step
         if (a.xt_hist != nullptr && in && c6 == 0.0f) {           // history = (xt, eps_theta) of the step, :217
           const int jh = (a.mode == MODE_CDDPM_DPM2) ? j >> 1 : j;
           const long long o = ((long long)jh * a.B + chain) * a.A + ai;
@@ -376,11 +444,51 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
       });
     }
 
-    sfor<NRX>([&](auto RI) {
-      constexpr int r = decltype(RI)::value;
-      const int ai = G::rowr(r) + 4 * ls;
-      if (valid && ai < a.AO) a.x0[chain * a.AO + ai] = xs[r];
-    });
+    if (EXT != 3 || a.x0 != nullptr) {
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const int ai = G::rowr(r) + 4 * ls;
+        if (valid && ai < a.AO) a.x0[chain * a.AO + ai] = xs[r];
+      });
+    }
+
+    if constexpr (EXT == 3) {
+      // ---------------- best-of-N: argmax (or Gumbel-max categorical) over the state's particles, dql.py:156-161 ----------
+      // A tile holds 32 / seg whole states of seg particles each (seg a power of two), or one 32-particle slice of a state.
+      const int seg = ct.seg;
+      float key = qmin;
+      if (ct.gumbel != nullptr) key = fmaf(qmin, ct.inv_temperature, (valid && ls == 0) ? ct.gumbel[chain] : 0.0f);
+      if (ct.q != nullptr && valid && ls == 0) ct.q[chain] = qmin;
+      key = __shfl(key, li);                                  // lanes 32 .. 63 take the key lanes 0 .. 31 hold
+      if (!valid) key = -__builtin_huge_valf();
+      int bi = valid ? tg * TR + (li & (seg - 1)) : 0x7fffffff;
+      for (int m = 1; m < seg; m <<= 1) {                     // larger key wins, equal keys -> the lower index (jnp.argmax)
+        const float ob = __shfl_xor(key, m);
+        const int oi = __shfl_xor(bi, m);
+        if (ob > key || (ob == key && oi < bi)) { key = ob; bi = oi; }
+      }
+      const int seg0 = (li & ~(seg - 1)) + TR * ls;           // first lane of the segment in this half: its verdict stands
+      key = __shfl(key, seg0);
+      bi = __shfl(bi, seg0);
+      const int wl = valid ? (li & ~(seg - 1)) + ((bi - tg * TR) & (TR - 1)) : li;
+      const bool better = (tg == 0) || key > gkey;            // strict >: the earlier slice keeps a tie
+      sfor<NRX>([&](auto RI) {
+        constexpr int r = decltype(RI)::value;
+        const float xw = __shfl(xs[r], wl + TR * ls);         // the winner's action rows, each half its own
+        if (better) gx[r] = xw;
+      });
+      if (better) { gkey = key; gbi = bi; }
+      if ((tg == n_tg - 1 || wt == n_wt - 1) && valid && (li & (seg - 1)) == 0) {
+        if (ls == 0 && ct.best_idx != nullptr) ct.best_idx[state] = gbi;
+        if (ct.best_action != nullptr) {
+          sfor<NRX>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            const int ai = G::rowr(r) + 4 * ls;
+            if (ai < a.A) ct.best_action[state * a.A + ai] = gx[r];
+          });
+        }
+      }
+    }
   }
 }
 
@@ -388,7 +496,15 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a) {
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_rs_kernel(const KArgs a) {
-  sampler_rs_body<TR, H, ACT, NRX, CKMAX, EXT>(a);
+  const CriticTab none{};
+  sampler_rs_body<TR, H, ACT, NRX, CKMAX, EXT>(a, none);
+}
+
+// The same with the critic tail (EXT 3): sampler + scoring + selection in one launch.
+template <int TR, int H, int ACT, int NRX, int CKMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+frl_sampler_rs_fused_kernel(const KArgs a, const CriticTab ct) {
+  sampler_rs_body<TR, H, ACT, NRX, CKMAX, 3>(a, ct);
 }
 
 // Two waves per SIMD, 256 registers per lane: the 16-chain geometry of the plain sampler (EXT 0: 249 registers, no
@@ -398,7 +514,8 @@ frl_sampler_rs_kernel(const KArgs a) {
 template <int ACT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 frl_sampler_rs_kernel_w2(const KArgs a) {
-  sampler_rs_body<16, 256, ACT, 4, 12, 0>(a);
+  const CriticTab none{};
+  sampler_rs_body<16, 256, ACT, 4, 12, 0>(a, none);
 }
 
 // ---- launcher --------------------------------------------------------------------------------------
@@ -416,16 +533,19 @@ static int device_cus_rs() {
 }
 
 // `configured`: the launching instantiation's per-device record of the dynamic-LDS size its kernel was last set up for
-static int launch_kern(const void* kern, const char* tag, size_t* configured, int TR, int H, int max_waves, const KArgs& a, hipStream_t stream) {
+static int launch_kern(const void* kern, const char* tag, size_t* configured, int TR, int H, int max_waves, const KArgs& a, hipStream_t stream,
+                       const CriticTab* ct = nullptr) {
   const int ncu = device_cus_rs();
-  const long long n_wt = (a.B + TR - 1) / TR;
+  const long long n_tiles = (a.B + TR - 1) / TR;
+  const long long n_wt = ct != nullptr ? (n_tiles + ct->group - 1) / ct->group : n_tiles;     // units a wave takes in turn
   long long per_cu = (n_wt + ncu - 1) / ncu;
   int nw = (int)(per_cu < 1 ? 1 : (per_cu > max_waves ? max_waves : per_cu));
   if (nw == 3) nw = 4;
   long long nwg = (n_wt + nw - 1) / nw;
   const int grid = (int)(nwg < ncu ? nwg : ncu);
   const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE +
-                                      (a.ws_ln != nullptr ? (size_t)a.L * 2 * H : 0));
+                                      (a.ws_ln != nullptr ? (size_t)a.L * 2 * H : 0) +
+                                      (ct != nullptr ? (size_t)ct->E * ((size_t)ct->L * H + LAST_PAD) : 0));
   if (lds > 160 * 1024) { set_error("sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -435,7 +555,9 @@ static int launch_kern(const void* kern, const char* tag, size_t* configured, in
     configured[dev] = lds;
   }
   KArgs args = a;
-  void* argv[] = {(void*)&args};
+  CriticTab cargs;
+  if (ct != nullptr) cargs = *ct;
+  void* argv[] = {(void*)&args, (void*)&cargs};
   hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(64 * nw), argv, lds, stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_error("sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
@@ -501,9 +623,33 @@ int launch_sampler_rs_act(const KArgs& a, hipStream_t stream) {
   return FRL_EUNSUPPORTED;
 }
 
+// sampler + critic scoring + selection in one launch (frl_sampler_select_fwd): the two 256-wide 32-chain geometries
+template <int TR, int H, int ACT, int NRX, int CKMAX>
+static int launch_fused_v(const KArgs& a, const CriticTab& ct, hipStream_t stream) {
+  static thread_local size_t configured[16] = {0};
+  char tag[112];
+  snprintf(tag, sizeof(tag), "frl_sampler_rs_fused_kernel<TR %d, H %d, act %d, NRX %d, CKMAX %d> [%d critics x %d layers]", TR, H, ACT, NRX, CKMAX, ct.E, ct.L);
+  return launch_kern((const void*)frl_sampler_rs_fused_kernel<TR, H, ACT, NRX, CKMAX>, tag, configured, TR, H, MAX_WAVES, a, stream, &ct);
+}
+
+template <int ACT>
+int launch_sampler_rs_fused_act(const KArgs& a, const CriticTab& ct, hipStream_t stream) {
+  if constexpr (ACT == FRL_ACT_IDENTITY) { set_error("fused critic: no identity-activation unit"); return FRL_EINVAL; }
+  else {
+    if (a.H != 256 || a.TR != 32 || a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr || a.L < 2 || ct.L < 2 || ct.E < 1 || ct.E > FUSE_MAX_E ||
+        ct.L > FUSE_MAX_L || ct.seg < 1 || ct.seg > 32 || (ct.seg & (ct.seg - 1)) != 0 || ct.group < 1 || (ct.group > 1 && ct.seg != 32)) {
+      set_error("fused critic: launch arguments outside the build (plan / launch mismatch)"); return FRL_EINVAL; }
+    if (a.AR <= 4 && a.CK <= 12) return launch_fused_v<32, 256, ACT, 4, 12>(a, ct, stream);
+    if (a.AR <= 12 && a.CK == 0) return launch_fused_v<32, 256, ACT, 12, 1>(a, ct, stream);
+    set_error("fused critic: x_dim %d with %d in-kernel condition rows has no build (wide actions need the per-state hoist)", a.A, a.C);
+    return FRL_EUNSUPPORTED;
+  }
+}
+
 #ifndef FRL_RS_ACT
 #error "compile with -DFRL_RS_ACT=<FRL_ACT_*>: one translation unit per activation"
 #endif
 template int launch_sampler_rs_act<FRL_RS_ACT>(const KArgs&, hipStream_t);
+template int launch_sampler_rs_fused_act<FRL_RS_ACT>(const KArgs&, const CriticTab&, hipStream_t);
 
 }  // namespace frl

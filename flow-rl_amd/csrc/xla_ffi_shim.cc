@@ -103,8 +103,9 @@ ffi::Error Marshal(const ffi::RemainingArgs& args, const ffi::Dictionary& attrs,
   d->time_dim = AttrOr<int32_t>(attrs, "time_dim", 64);
   d->act = AttrOr<int32_t>(attrs, "act", FRL_ACT_MISH);
   d->clip = AttrOr<int32_t>(attrs, "clip", 0);
-  d->x_min = AttrOr<float>(attrs, "x_min", 0.0f);
-  d->x_max = AttrOr<float>(attrs, "x_max", 0.0f);
+  // an absent side is unbounded, as jnp.clip(x, None, None) leaves it (ddpm.py:200-201, cnf.py:109-110)
+  d->x_min = AttrOr<float>(attrs, "x_min", -__builtin_huge_valf());
+  d->x_max = AttrOr<float>(attrs, "x_max", __builtin_huge_valf());
   d->dtype = AttrOr<int32_t>(attrs, "dtype", FRL_DTYPE_F32);
   d->want_history = AttrOr<int32_t>(attrs, "want_history", 0);
   d->cond_embed = AttrOr<int32_t>(attrs, "cond_embed", 0);
@@ -247,7 +248,13 @@ ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
     if (d.time_embed == FRL_TEMB_FOURIER && !Output<float>(rets, out++, ffi::DataType::F32, &b.grad_time_kernel))
       return Invalid("native_time = 1 with a Fourier embedding: result grad time_embedding/kernel");
   } else {
-    b.grad_bias[0] = nullptr;      // the binding differentiates the time branch itself from grad_tb (jax.vjp)
+    // the binding differentiates the time branch itself from grad_tb (jax.vjp): the library leaves grad_bias_0 alone, so
+    // the result buffer is zero-filled here rather than handed back uninitialised (the binding ADDS its own term)
+    auto gb0 = rets.get<ffi::AnyBuffer>(2);
+    if (gb0.has_value() && b.grad_bias[0] != nullptr &&
+        hipMemsetAsync(b.grad_bias[0], 0, (size_t)(*gb0)->element_count() * sizeof(float), stream) != hipSuccess)
+      return ffi::Error(ffi::ErrorCode::kInternal, "zero-fill of grad_bias_0 failed");
+    b.grad_bias[0] = nullptr;
   }
   if (d.cond_embed)
     for (int k = 0; k < 2; ++k)

@@ -18,4 +18,10 @@ from . import model  # noqa: F401  (Model.apply_gradient: TrainState, adam, clip
 from .module import (DDPMBackbone, FlowBackbone, ContinuousDDPMBackbone, MLP, ResidualMLP, Simba, PositionalEmbedding,  # noqa: F401
                      LearnableFourierEmbedding, init_params, tree_from_numpy, tree_to)
 from ._lib import FlowRLHipError, FlowRLHipUnsupported  # noqa: F401
-from .critic import Ensemblize, ScalarCritic, critic_select, init_critic_params, sample_and_select  # noqa: F401
+from .critic import Ensemblize, FusedSelect, ScalarCritic, critic_select, init_critic_params, sample_and_select  # noqa: F401
+
+
+def last_kernels() -> str:
+    """Names (and launch geometry) of the kernels the calling thread's last library call enqueued (frl_last_kernels)."""
+    from . import _lib
+    return _lib.load().frl_last_kernels().decode()

@@ -139,6 +139,10 @@ EXPORTS = {
     "frl_critic_workspace_bytes": (C.c_size_t, [C.POINTER(FrlCriticDesc)]),
     "frl_critic_select": (C.c_int, [C.POINTER(FrlCriticDesc), C.POINTER(FrlCriticParams), C.POINTER(FrlSelectBufs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frl_sampler_select_workspace_bytes": (C.c_size_t, [C.POINTER(FrlDesc), C.POINTER(FrlCriticDesc)]),
+    "frl_sampler_select_fwd": (C.c_int, [C.POINTER(FrlDesc), C.POINTER(FrlParams), C.POINTER(FrlSchedule), C.POINTER(FrlFwdBufs),
+                                         C.POINTER(FrlCriticDesc), C.POINTER(FrlCriticParams), C.POINTER(FrlSelectBufs),
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "frl_random_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "frl_random_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "frl_random_bits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -275,8 +275,11 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
                 clip_sampler: bool, x_min, x_max, history: bool, particles: Optional[int] = None,
                 compute_dtype: str = "f32", tile_policy: str = "auto", rng_key: Optional[torch.Tensor] = None,
                 rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard: Optional[Tuple[int, int]] = None,
-                static_scratch: bool = False):
-    """``rng_shard`` = (first chain, total chains) when this call is one state-shard of a larger batch: the in-kernel
+                static_scratch: bool = False, select=None):
+    """``select`` (a :class:`flowrl_hip.critic.FusedSelect`): critic scoring and best-of-N selection run inside the
+    sampler's launch (frl_sampler_select_fwd); its ``best`` / ``idx`` / ``q`` fields receive the outputs and x0 is only
+    materialised when it asks for the candidates.
+    ``rng_shard`` = (first chain, total chains) when this call is one state-shard of a larger batch: the in-kernel
     draws are then the elements of the UNSHARDED normal(key_j, (total, A)), so N ranks reproduce one big call.
     Returns (x0, (xt_hist, eps_hist) or (None, None)) with xT's leading dims restored — and, when ``rng_key`` (a (2,)
     uint32 threefry key, flowrl_hip.random) is given, a third element: the rng the reference's sample() returns; the
@@ -302,9 +305,16 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
         rng_impl=0 if rng_key is None else _random.impl_id(rng_impl))
 
     x_in = _f32c(xT.reshape(B, A), device, "xT")
-    x0 = torch.empty((B, A), dtype=torch.float32, device=device)
     bufs = _lib.FrlFwdBufs()
-    bufs.xT, bufs.x0 = x_in.data_ptr(), x0.data_ptr()
+    if select is not None:
+        if static_scratch or cache_prepare or history or rng_key is not None:
+            raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "fused sample+select: no static_scratch / cache_prepare / history / in-kernel rng")
+        x0 = torch.empty((B, A), dtype=torch.float32, device=device) if select.want_actions else None
+    else:
+        x0 = torch.empty((B, A), dtype=torch.float32, device=device)
+    bufs.xT = x_in.data_ptr()
+    if x0 is not None:
+        bufs.x0 = x0.data_ptr()
     if cond2d is not None:
         bufs.cond = cond2d.data_ptr()
     if noise is not None:
@@ -313,6 +323,19 @@ def run_sampler(network, params: Dict, *, kind: int, solver: int, steps: int, xT
         noise = _f32c(noise.reshape(steps, B, A), device, "noise")
         bufs.noise = noise.data_ptr()
     rng_out = None
+    if select is not None:
+        cdesc, cparams, sbufs, ckeep = select.marshal(int(desc.n_states), int(desc.particles), A, device)
+        need = lib.frl_sampler_select_workspace_bytes(C.byref(desc), C.byref(cdesc))
+        stream = torch.cuda.current_stream(device).cuda_stream
+        ws = _workspace(max(need, 256), device, stream)
+        with torch.cuda.device(device):      # need == 0: the entry point says why (raises through check)
+            rc = lib.frl_sampler_select_fwd(C.byref(desc), C.byref(fparams), C.byref(fs), C.byref(bufs), C.byref(cdesc), C.byref(cparams),
+                                            C.byref(sbufs), ws.data_ptr() if need else None, ws.numel() if need else 0, stream)
+        _lib.check(rc)
+        if need == 0:
+            raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "fused sample+select: configuration has no kernel")
+        del ckeep
+        return (x0.reshape(*lead, A) if x0 is not None else None), (None, None)
     if rng_key is not None:
         rng_key = _random.as_key(rng_key, device)
         rng_out = torch.empty((2,), dtype=torch.uint32, device=device)

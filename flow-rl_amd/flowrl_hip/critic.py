@@ -27,6 +27,9 @@ from ._sampler import _f32c, _workspace
 from .module import MLP, _dense, tree_to
 
 
+FUSED_MIN_CHAINS = 32768        # sample_and_select(fused="auto"): below this the separate launches' latency builds win
+
+
 @dataclass
 class ScalarCritic:
     backbone: MLP
@@ -54,24 +57,12 @@ def init_critic_params(critic: Ensemblize, obs_dim: int, act_dim: int, seed: int
     return tree_to(p, device)
 
 
-def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor], actions: torch.Tensor, num_samples: int,
-                  *, temperature: Optional[float] = 0.0, gumbel: Optional[torch.Tensor] = None,
-                  want_q: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
-    """``obs`` (B, S) UN-repeated, ``actions`` (B, N, A) or (B*N, A).  Returns (best actions (B, A), idx (B,) int32,
-    qs (B, N) = min over the ensemble).  temperature <= 0: argmax (dql.py:156-157); temperature > 0: the categorical
-    draw of dql.py:158-160 as argmax(qs / (1e-6 + T) + gumbel) with ``gumbel`` (B, N) supplied by the caller."""
-    lib = _lib.load()
-    if not actions.is_cuda:
-        raise RuntimeError("flowrl_hip critic scoring runs on the GPU only; there is no CPU fallback")
-    dev = actions.device
+def _critic_marshal(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor], B: int, N: int, A: int, dev: torch.device,
+                    temperature: Optional[float], gumbel: Optional[torch.Tensor], want_q: bool):
+    """FrlCriticDesc / FrlCriticParams / FrlSelectBufs of one scoring call and its output tensors (best, idx, q)."""
     mlp = critic.base.backbone
     if mlp.layer_norm or (mlp.dropout and mlp.dropout > 0) or mlp.output_dim:
         raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "critic backbone must be a plain MLP (no layer_norm / dropout / output layer)")
-    A = actions.shape[-1]
-    N = int(num_samples)
-    B = actions.numel() // (A * N)
-    if B * N * A != actions.numel():
-        raise ValueError("actions do not hold num_samples candidates per state")
     S = 0 if obs is None else obs.shape[-1]
     if obs is not None and obs.numel() != B * S:
         raise ValueError(f"obs has {obs.numel() // max(S, 1)} rows, expected {B} (un-repeated)")
@@ -94,10 +85,9 @@ def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor],
         keep += [k, b]
         fp.kernel[i], fp.bias[i] = k.data_ptr(), b.data_ptr()
     bufs = _lib.FrlSelectBufs()
-    act2 = _f32c(actions.reshape(B * N, A), dev, "actions")
-    bufs.actions = act2.data_ptr()
     if obs is not None:
         obs2 = _f32c(obs.reshape(B, S), dev, "obs")
+        keep.append(obs2)
         bufs.obs = obs2.data_ptr()
     if temperature is not None and temperature > 0.0:
         if gumbel is None:
@@ -111,6 +101,27 @@ def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor],
     if q is not None:
         bufs.q = q.data_ptr()
     bufs.best_idx, bufs.best_action = idx.data_ptr(), best.data_ptr()
+    return d, fp, bufs, keep, (best, idx, q)
+
+
+def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor], actions: torch.Tensor, num_samples: int,
+                  *, temperature: Optional[float] = 0.0, gumbel: Optional[torch.Tensor] = None,
+                  want_q: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """``obs`` (B, S) UN-repeated, ``actions`` (B, N, A) or (B*N, A).  Returns (best actions (B, A), idx (B,) int32,
+    qs (B, N) = min over the ensemble).  temperature <= 0: argmax (dql.py:156-157); temperature > 0: the categorical
+    draw of dql.py:158-160 as argmax(qs / (1e-6 + T) + gumbel) with ``gumbel`` (B, N) supplied by the caller."""
+    lib = _lib.load()
+    if not actions.is_cuda:
+        raise RuntimeError("flowrl_hip critic scoring runs on the GPU only; there is no CPU fallback")
+    dev = actions.device
+    A = actions.shape[-1]
+    N = int(num_samples)
+    B = actions.numel() // (A * N)
+    if B * N * A != actions.numel():
+        raise ValueError("actions do not hold num_samples candidates per state")
+    d, fp, bufs, keep, (best, idx, q) = _critic_marshal(critic, params, obs, B, N, A, dev, temperature, gumbel, want_q)
+    act2 = _f32c(actions.reshape(B * N, A), dev, "actions")
+    bufs.actions = act2.data_ptr()
     need = lib.frl_critic_workspace_bytes(C.byref(d))
     if need == 0:
         _lib.check(lib.frl_critic_select(C.byref(d), C.byref(fp), C.byref(bufs), None, 0, None))
@@ -123,16 +134,38 @@ def critic_select(critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor],
     return best, idx, q
 
 
+class FusedSelect:
+    """Critic scoring + selection carried INSIDE the sampler's launch (frl_sampler_select_fwd): pass as ``select=`` to a
+    model's ``sample``; afterwards ``best`` (B, A), ``idx`` (B,) int32 and ``q`` (B, N) (``want_q``) hold what
+    :func:`critic_select` would have returned for the sampled candidates, which are only written out (the sample call's
+    actions) with ``want_actions``."""
+
+    def __init__(self, critic: Ensemblize, params: Dict, obs: Optional[torch.Tensor], *, temperature: Optional[float] = 0.0,
+                 gumbel: Optional[torch.Tensor] = None, want_q: bool = False, want_actions: bool = False):
+        self.critic, self.params, self.obs = critic, params, obs
+        self.temperature, self.gumbel, self.want_q, self.want_actions = temperature, gumbel, want_q, want_actions
+        self.best = self.idx = self.q = None
+
+    def marshal(self, n_states: int, particles: int, A: int, dev: torch.device):
+        d, fp, bufs, keep, (self.best, self.idx, self.q) = _critic_marshal(
+            self.critic, self.params, self.obs, n_states, particles, A, dev, self.temperature, self.gumbel, self.want_q)
+        return d, fp, bufs, keep
+
+
 def sample_and_select(model, critic: Ensemblize, critic_params: Dict, rng, obs: torch.Tensor, training: bool, num_samples: int,
                       solver: str, temperature: Optional[float], *, xT: Optional[torch.Tensor] = None,
                       noise: Optional[torch.Tensor] = None, gumbel: Optional[torch.Tensor] = None, compute_dtype: str = "f32",
-                      rng_impl: Optional[str] = None):
+                      rng_impl: Optional[str] = None, fused="auto"):
     """jit_sample_and_select (dql.py:130-162): num_samples chains per observation, then the critic picks one.
     With a threefry key as ``rng`` (flowrl_hip.random.PRNGKey) the call is the reference's rng-in / rng-out protocol,
     all on the GPU: ``rng, xT_rng = split(rng)``; ``xT = normal(xT_rng, (B, N, A))``; the sampler draws its noise
     in-kernel and advances the rng; ``rng, select_rng = split(rng)`` and Gumbel-max over ``gumbel(select_rng, (B, N))``
     when temperature > 0.  Otherwise ``xT`` (B, N, A) / ``noise`` / ``gumbel`` are the reference's draws supplied by the
-    caller (torch draws when absent) and ``rng`` is returned unchanged."""
+    caller (torch draws when absent) and ``rng`` is returned unchanged.
+    ``fused``: True = one launch for sampler + critic + selection (frl_sampler_select_fwd; raises when the configuration
+    has no such build), False = sampler launch, critic launches, selection launch; "auto" = fused when the build exists
+    and the batch is throughput-sized (>= FUSED_MIN_CHAINS chains), else the separate launches (whose small-batch
+    latency builds the fused kernel does not have).  The fused path needs caller-side draws (no threefry key)."""
     from . import random as fr
     B = obs.shape[0]
     keyed = fr.is_key(rng)
@@ -142,8 +175,26 @@ def sample_and_select(model, critic: Ensemblize, critic_params: Dict, rng, obs: 
             xT = fr.normal(xT_rng, (B, num_samples, model.x_dim), rng_impl)                              # dql.py:146
     elif xT is None:
         xT = torch.randn((B, num_samples, model.x_dim), dtype=torch.float32, device=obs.device)
-    kw = dict(rng_impl=rng_impl) if keyed else {}
-    rng, actions, _ = model.sample(rng, xT, obs, training, solver, noise=noise, particles=num_samples, compute_dtype=compute_dtype, **kw)
+    import inspect
+    accepted = inspect.signature(model.sample).parameters          # CNF.sample has neither solver nor noise
+    kw = dict(noise=noise, particles=num_samples, compute_dtype=compute_dtype)
+    if keyed:
+        kw["rng_impl"] = rng_impl
+    if solver is not None:
+        kw["solver"] = solver
+    kw = {k: v for k, v in kw.items() if k in accepted}
+    can_fuse = temperature is not None and not keyed and compute_dtype == "f32" and (temperature <= 0.0 or gumbel is not None)
+    if fused is True and not can_fuse:
+        raise _lib.FlowRLHipUnsupported(_lib.FRL_EUNSUPPORTED, "fused sample+select: needs a temperature, caller-side draws (no threefry key, gumbel given) and f32")
+    if can_fuse and (fused is True or (fused == "auto" and B * num_samples >= FUSED_MIN_CHAINS)):
+        sel = FusedSelect(critic, critic_params, obs, temperature=temperature, gumbel=gumbel)
+        try:
+            model.sample(rng, xT, obs, training, select=sel, **kw)
+            return rng, sel.best
+        except _lib.FlowRLHipUnsupported:
+            if fused is True:
+                raise
+    rng, actions, _ = model.sample(rng, xT, obs, training, **kw)
     if temperature is None:
         return rng, actions[:, 0]                                           # dql.py:148-149
     if keyed and temperature > 0.0:

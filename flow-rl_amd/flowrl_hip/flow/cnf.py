@@ -39,7 +39,7 @@ class ContinuousNormalizingFlow:
 
     def sample(self, rng, x0: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                params: Optional[Dict] = None, *, history: bool = False, particles: Optional[int] = None,
-               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False):
+               compute_dtype: str = "f32", tile_policy: str = "auto", rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False, select=None):
         """ContinuousNormalizingFlow.sample (cnf.py:113-141): Euler steps t = k/steps, x += vel/steps.  A (2,) uint32
         threefry key as ``rng`` is advanced as the reference's scan does (cnf.py:126) and returned; anything else is
         returned unchanged.
@@ -59,7 +59,7 @@ class ContinuousNormalizingFlow:
             self.network, p, kind=_lib.FRL_KIND_CNF, solver=_lib.FRL_SOLVER_EULER, steps=self.steps, xT=x0,
             condition=condition, noise=None, sched={}, clip_sampler=bool(self.clip_sampler), x_min=self.x_min,
             x_max=self.x_max, history=history, particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy,
-            rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch)
+            rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch, select=select)
         return (out[2] if key is not None else rng), out[0], out[1]
 
     # ---- training-side half ---------------------------------------------------------------------

@@ -83,7 +83,7 @@ class ContinuousDDPM:
                solver: Optional[str] = None, steps: Optional[int] = None, t_schedule_n: Optional[float] = None,
                params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None, history: bool = False,
                particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False):
+               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False, select=None):
         """ContinuousDDPM.sample (continuous_ddpm.py:117-222).
         ``rng``: a (2,) uint32 threefry key (flowrl_hip.random.PRNGKey / jax.random.key_data) makes the call a
         true rng-in / rng-out drop-in: the scan's split sequence runs on the GPU, the per-step noise is drawn in-kernel
@@ -113,7 +113,7 @@ class ContinuousDDPM:
             self.network, p, kind=_lib.FRL_KIND_CDDPM, solver=solver_ids[solver],
             steps=steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None, sched=sched,
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch)
+            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch, select=select)
         return (out[2] if key is not None else rng), out[0], out[1]
 
     # ---- training-side half ---------------------------------------------------------------------

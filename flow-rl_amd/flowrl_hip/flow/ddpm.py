@@ -67,7 +67,7 @@ class DDPM:
     def sample(self, rng, xT: torch.Tensor, condition: Optional[torch.Tensor] = None, training: bool = False,
                solver: str = "ddpm", params: Optional[Dict] = None, *, noise: Optional[torch.Tensor] = None,
                history: bool = False, particles: Optional[int] = None, compute_dtype: str = "f32", tile_policy: str = "auto",
-               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+               rng_impl: Optional[str] = None, cache_prepare: bool = False, rng_shard=None, static_scratch: bool = False, keep_for_vjp: bool = False, select=None) -> Tuple[object, torch.Tensor, Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
         """DDPM.sample (ddpm.py:173-221).  Extra keyword-only arguments:
         ``noise`` (T, *xT.shape): the per-iteration N(0, I) draws (iteration j <-> t = T - j);
         ``history``: also return (xt_hist, eps_hist) (ddpm.py:217); ``particles``: chains per condition
@@ -98,7 +98,7 @@ class DDPM:
             steps=self.steps, xT=xT, condition=condition, noise=noise if solver == "ddpm" else None,
             sched={"betas": self.betas, "alphas": self.alphas, "alpha_hats": self.alpha_hats, "postvars": self.postvars},
             clip_sampler=bool(self.clip_sampler), x_min=self.x_min, x_max=self.x_max, history=history,
-            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch)
+            particles=particles, compute_dtype=compute_dtype, tile_policy=tile_policy, rng_key=key, rng_impl=rng_impl, cache_prepare=cache_prepare, rng_shard=rng_shard, static_scratch=static_scratch, select=select)
         return (out[2] if key is not None else rng), out[0], out[1]
 
     # ---- training-side half ---------------------------------------------------------------------

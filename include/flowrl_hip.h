@@ -328,6 +328,20 @@ size_t frl_critic_workspace_bytes(const FrlCriticDesc* desc);
 int frl_critic_select(const FrlCriticDesc* desc, const FrlCriticParams* params, const FrlSelectBufs* bufs,
                       void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Sampler + critic scoring + selection in ONE launch (SURVEY 8(f) rank 1 as written: jit_sample_and_select dql.py:130-162,
+ * jit_sample_actions qvpo.py:21-44).  frl_sampler_fwd followed by frl_critic_select, except that the candidate actions
+ * never leave the chip: after the last step the E critic members are evaluated on each tile's x0 in registers, the minimum
+ * over the ensemble and the argmax / Gumbel-max over a state's particles are taken in the kernel, and only best_action
+ * (n_states, A) / best_idx (n_states,) / optionally q (n_states, particles) are written.  fwd.x0 may be NULL (it is written
+ * when given); sel.actions is ignored.  This build: f32 MLP sampler, 256 wide, no LayerNorm, caller-supplied noise; critic
+ * backbone 256 wide, <= 4 hidden layers, <= 4 members, activation = the sampler's or relu (QVPO: mish actor, relu critic);
+ * particles a power of two <= 32 or a multiple of 32; cdesc.n_states / particles / act_dim = desc.n_states / particles /
+ * x_dim.  Anything else: FRL_EUNSUPPORTED (use the two calls). */
+size_t frl_sampler_select_workspace_bytes(const FrlDesc* desc, const FrlCriticDesc* cdesc);
+int frl_sampler_select_fwd(const FrlDesc* desc, const FrlParams* params, const FrlSchedule* sched, const FrlFwdBufs* fwd,
+                           const FrlCriticDesc* cdesc, const FrlCriticParams* cparams, const FrlSelectBufs* sel,
+                           void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Algorithmic FLOPs of one call, SURVEY.md section 8(d): 2*B*T*(K0*H + sum H_l*H_{l+1} + H*A) with
  * the reference's full K0 = A + D' + C; `executed` (may be NULL) receives the MFMA FLOPs the kernel
  * really issues (time slice hoisted, edge layers zero-padded). */
