@@ -406,6 +406,10 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
     ap.add_argument("--recompute", action="store_true", help="cfg5: plain forward with history + a backward that recomputes every step (round-1 path) instead of the training forward's stash")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU / gloo stand-in of the rank body (no GPU, not a measurement)")
+    ap.add_argument("--select", default="none", choices=["none", "fused", "separate"],
+                    help="multi-particle workloads: a step is sample + critic scoring + best-of-N selection (jit_sample_and_select / "
+                         "jit_sample_actions) with an Ensemblize(ScalarCritic(MLP 256x2 relu)) x 2 critic; fused = one launch "
+                         "(frl_sampler_select_fwd), separate = frl_sampler_fwd + frl_critic_select")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank owns the workload's per-GPU batch; strong: the workload's TOTAL batch (SURVEY 8(d): cfg4 = "
                          "65536 states x 64 particles, cfg3 = 8388608 chains; others: the per-GPU batch) is split over the ranks by state index "
@@ -477,6 +481,27 @@ def main():
         w["rng_shard"] = (rank * B, world * B) if total_chains is None else (sum(shard_counts[:rank]), total_chains)
 
     vjp = bool(w.get("vjp"))
+    critic = cparams = None
+    if args.select != "none":
+        import flowrl_hip as fh
+        if vjp or args.rng != "none" or args.dtype != "f32":
+            ap.error("--select: forward f32 workloads with caller-supplied noise")
+        critic = fh.Ensemblize(base=fh.ScalarCritic(backbone=fh.MLP(hidden_dims=[256, 256], activation="relu")), ensemble_size=2)
+        cparams = fh.init_critic_params(critic, S, A, seed=7, bias_std=0.1, device=dev)
+
+    def sample_select():
+        import flowrl_hip as fh
+        parts = w["particles"] if w["particles"] > 1 else None
+        x3 = xT.reshape(B // w["particles"], w["particles"], A) if parts else xT
+        pos = (None, x3, cond) if w["kind"] == "cnf" else (None, x3, cond, False, "ddpm")
+        kw = dict(particles=parts) if w["kind"] == "cnf" else dict(particles=parts, noise=noise)
+        if args.select == "fused":
+            sel = fh.FusedSelect(critic, cparams, cond, temperature=0.0)
+            model.sample(*pos, select=sel, **kw)
+            return sel.best
+        x0 = model.sample(*pos, tile_policy=args.tile_policy, **kw)[1]
+        return fh.critic_select(critic, cparams, cond, x0, w["particles"], temperature=0.0, want_q=False)[0]
+
     g_x0 = torch.randn((B, A), generator=torch.Generator(device=dev).manual_seed(99 + rank), device=dev) / (total_chains if total_chains is not None else world * B) if vjp else None
 
     def step():
@@ -486,6 +511,8 @@ def main():
             if world > 1 and not args.no_gather:
                 parallel.all_reduce_grads(grads)
             return x0
+        if critic is not None:
+            return sample_select()           # (n_states, A) chosen actions; the gather of a multi-GPU run is left out
         x0 = sample(model, w, xT, cond, noise)
         if world > 1 and not args.no_gather:
             if total_chains is None:
@@ -554,6 +581,12 @@ def main():
         }
         if vjp:
             out["roofline"].update(vjp_parts)
+        if critic is not None:
+            from flowrl_hip import _lib as _fl2
+            sample_select()
+            out["config"]["select"] = {"mode": args.select, "critic": "Ensemblize(ScalarCritic(MLP 256x2 relu)) x 2, argmax",
+                                       "kernels": _fl2.load().frl_last_kernels().decode(),
+                                       "note": "ms_per_step / value cover sampler + scoring + selection; roofline.* is the sampler kernel alone (frl_sampler_run)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
     if world > 1:

@@ -289,8 +289,18 @@ frl_sampler_bf16_kernel(const KArgs a) {
       // ---------------- Dense_L : O = b_L + W_L^T h_{L-1}, one output block ----------------------------
       f32x16 O;
       sfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[BF_ROWR(r) + 4 * ls]; });
+      // this step's noise: requested at the head of Dense_L (16 MFMAs before its use) instead of in the epilogue, where the
+      // wait for it also drained the stream's DMA pieces issued since (vector-memory results return in issue order).
+      // A/B'd and dropped in round 3: issuing the refill pieces one per 8 MFMAs instead of four at the chunk boundary
+      // (0.49 -> 0.57 ms: a DMA issued inside the MFMA / ds_read stream costs more than four behind the barrier).
+      float zn[NRX];
       {
         const char* sl = next_chunk() + lane16;
+        sfor<NRX>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int ai = BF_ROWR(r) + 4 * ls;
+          zn[r] = (a.noise != nullptr && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        });
         u32x4 awl[4];
         sfor<4>([&](auto KI) { constexpr int ks = decltype(KI)::value; awl[ks] = *(const u32x4*)(sl + ks * 1024); });
         sfor<16>([&](auto KI) {
@@ -310,8 +320,7 @@ frl_sampler_bf16_kernel(const KArgs a) {
         const int ai = BF_ROWR(r) + 4 * ls;
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
-        // noise is read here, not a step ahead: the second wave on the SIMD covers the latency, registers are scarce
-        float z = (a.noise != nullptr && in) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
+        float z = zn[r];
         if (a.rng_impl != FRL_RNG_NONE && in && c5 != 0.0f) {   // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai]; the
                                                                    // last iteration multiplies its draw by 0 (ddpm.py:206): skipped
           z = rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai);

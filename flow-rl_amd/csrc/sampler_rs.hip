@@ -48,12 +48,23 @@ __device__ __forceinline__ f32x2 rs_act2(f32x2 x) {
 #endif
 }
 
-// EXT: 0 plain, 1 rarer solvers / evaluation / hoisted condition rows, 2 = 1 + in-kernel draws + LayerNorm,
-//      3 = 1 + critic scoring and best-of-N selection on the finished tile (CriticTab, frl_internal.h)
+// A pointer read from the critic's device-side table, as the wave-uniform value it is: without this the descriptors built
+// from it live in vector registers and every buffer load is wrapped in a readfirstlane loop.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
+// EXT: 0 plain, 1 rarer solvers / evaluation / hoisted condition rows, 2 = 1 + LayerNorm,
+//      3 = 1 + critic scoring and best-of-N selection on the finished tile (CriticTab, frl_internal.h), 4 = 3 with a relu critic,
+//      5 = 1 + in-kernel threefry draws as micro-steps behind the MFMAs of the first hidden layer (no LayerNorm code: its
+//          presence alone costs the hot loops ~4 % in accumulator moves; LayerNorm + draws = EXT 2, draws up front)
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
 __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab& ct) {
   typedef Geo<TR> G;
   typedef typename G::acc_t acc_t;
+  constexpr bool HAS_LN = (EXT == 2), HAS_RNG = (EXT == 5), HAS_CRITIC = (EXT == 3 || EXT == 4);
   constexpr int KS = G::KS, NR = G::NR, RING = G::RING;
   constexpr int NB = H / TR;        // output (and input) feature blocks per hidden layer
   constexpr int NG = NB / 4;        // 16-byte A-operand loads per k-step
@@ -82,7 +93,7 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
   for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
   float* s_ln = s_coef + a.NE * COEF_STRIDE;          // EXT 2, LayerNorm backbones only: [L][2][H] scale | bias rows
-  if constexpr (EXT == 2) {
+  if constexpr (HAS_LN) {
     if (a.ws_ln != nullptr)
       for (int idx = tid; idx < a.L * 2 * H; idx += blockDim.x) s_ln[idx] = a.ws_ln[idx];
   }
@@ -90,18 +101,18 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
   float* s_ctb = s_ln;
   float* s_cbh = s_ctb;
   float* s_cbl = s_ctb;
-  if constexpr (EXT == 3) {
+  if constexpr (HAS_CRITIC) {
     static_assert(TR == 32, "fused critic: 32-chain tiles");
     s_cbh = s_ctb + ct.E * H;
     s_cbl = s_cbh + ct.E * (ct.L - 1) * H;
     for (int e = 0; e < ct.E; ++e) {
-      const float* tp = ct.ptrs[e * CT_STRIDE + CT_TB];
+      const float* tp = uniform_ptr(ct.ptrs[e * CT_STRIDE + CT_TB]);
       for (int idx = tid; idx < H; idx += blockDim.x) s_ctb[e * H + idx] = tp[idx];
       for (int l = 1; l < ct.L; ++l) {
-        const float* bp = ct.ptrs[e * CT_STRIDE + CT_BH + l - 1];
+        const float* bp = uniform_ptr(ct.ptrs[e * CT_STRIDE + CT_BH + l - 1]);
         for (int idx = tid; idx < H; idx += blockDim.x) s_cbh[(e * (ct.L - 1) + l - 1) * H + idx] = bp[idx];
       }
-      if (tid < LAST_PAD) s_cbl[e * LAST_PAD + tid] = ct.ptrs[e * CT_STRIDE + CT_BLP][tid];
+      if (tid < LAST_PAD) s_cbl[e * LAST_PAD + tid] = uniform_ptr(ct.ptrs[e * CT_STRIDE + CT_BLP])[tid];
     }
   }
   __syncthreads();
@@ -205,12 +216,12 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
 
   // EXT 3: a state's particles fill `group` CONSECUTIVE tiles, which one wave takes in turn (the running maximum over
   // the state's candidates stays in its registers); every other build: one tile per turn
-  const int n_tg = (EXT == 3) ? ct.group : 1;
+  const int n_tg = (HAS_CRITIC) ? ct.group : 1;
   const int n_grp = (n_wt + n_tg - 1) / n_tg;
   float gkey = 0.0f;          // EXT 3: best selection key of the state so far, its particle index and its action
   int gbi = 0;
-  float gx[EXT == 3 ? NRX : 1];
-  sfor<(EXT == 3 ? NRX : 1)>([&](auto RI) { gx[decltype(RI)::value] = 0.0f; });
+  float gx[HAS_CRITIC ? NRX : 1];
+  sfor<(HAS_CRITIC ? NRX : 1)>([&](auto RI) { gx[decltype(RI)::value] = 0.0f; });
 
   for (int grp = blockIdx.x * nw + wave; grp < n_grp; grp += gridDim.x * nw)
   for (int tg = 0; tg < n_tg; ++tg) {
@@ -239,42 +250,58 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
 
     // one iteration per network evaluation (= per sampler step, except dpm2: two); EXT 3: then one per critic member on
     // the finished x0 (same Dense_0 / hidden / head code, the member's tables; the operand prefetches chain through)
-    const int n_ev = a.NE + (EXT == 3 ? ct.E : 0);
+    // One network evaluation: a sampler step (CRIT false; dpm2: half a step), or — EXT 3, on the finished x0 — critic
+    // member ce (CRIT true: the member's tables, activation AC, no update rule).  Each use below is its own copy of the
+    // code, so the sampler's loops are exactly those of the EXT 1 build; the operand prefetches chain through from one
+    // evaluation to the next (last step -> member 0 -> ... -> the next tile's first step).
     float qmin = 0.0f;
-    for (int j = 0; j < n_ev; ++j) {
-      const bool crit = (EXT == 3) && j >= a.NE;            // this evaluation is critic member ce
-      const int ce = crit ? j - a.NE : 0;
-      const int jn = (j + 1 < n_ev) ? j + 1 : 0;            // the evaluation whose first operands are prefetched
-      const bool critn = (EXT == 3) && jn >= a.NE;
+    auto eval_body = [&](auto CRIT_T, auto AK, const int j, const int ce) __attribute__((always_inline)) {
+      constexpr bool crit = decltype(CRIT_T)::value;
+      constexpr int AC = decltype(AK)::value;
+      const bool critn = crit ? (ce + 1 < ct.E) : ((HAS_CRITIC) && j + 1 == a.NE);   // the NEXT evaluation is a critic member
+      const int cen = crit ? ce + 1 : 0;
       const int Lj = crit ? ct.L : a.L;
       const int jc = crit ? 0 : j;                          // row of the coefficient / time-bias tables
-      const __amdgpu_buffer_rsrc_t rs0c = crit ? __builtin_amdgcn_make_buffer_rsrc((void*)ct.ptrs[ce * CT_STRIDE + CT_W0P], 0, ct.w0p_bytes, 0x00020000) : rs0;
-      const __amdgpu_buffer_rsrc_t rs0n = critn ? __builtin_amdgcn_make_buffer_rsrc((void*)ct.ptrs[(jn - a.NE) * CT_STRIDE + CT_W0P], 0, ct.w0p_bytes, 0x00020000) : rs0;
-      const __amdgpu_buffer_rsrc_t rslc = crit ? __builtin_amdgcn_make_buffer_rsrc((void*)ct.ptrs[ce * CT_STRIDE + CT_WLQ], 0, NK * 64 * 4, 0x00020000) : rsl;
+      __amdgpu_buffer_rsrc_t rs0c = rs0, rs0n = rs0, rslc = rsl;
+      if constexpr (HAS_CRITIC) {
+        if constexpr (crit) {
+          rs0c = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(ct.ptrs[ce * CT_STRIDE + CT_W0P]), 0, ct.w0p_bytes, 0x00020000);
+          rslc = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(ct.ptrs[ce * CT_STRIDE + CT_WLQ]), 0, NK * 64 * 4, 0x00020000);
+        }
+        if (critn) rs0n = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(ct.ptrs[cen * CT_STRIDE + CT_W0P]), 0, ct.w0p_bytes, 0x00020000);
+      }
       auto live = [&](int n) { return n < NRX ? n < a.AR : (!crit && (n - NRX) < a.CK); };
-      // the critic's activation: the sampler's compiled one, or relu (QVPO / DACER critics beside a mish actor)
-      auto act2 = [&](f32x2 x) __attribute__((always_inline)) {
-        f32x2 y = rs_act2<ACT>(x);
-        if constexpr (EXT == 3 && ACT != FRL_ACT_RELU) { if (crit && ct.relu) y = f32x2{act_fn<FRL_ACT_RELU>(x[0]), act_fn<FRL_ACT_RELU>(x[1])}; }
-        return y;
-      };
       float zr[NRX];
-      if constexpr (EXT == 2) {
-        // in-kernel jax.random.normal(key_j, xt.shape)[chain, ai] (frl_rng.h), drawn while no accumulator is live
-        if (a.rng_impl != FRL_RNG_NONE) {
-          const bool used = s_coef[j * COEF_STRIDE + 5] != 0.0f;   // c5 = 0: the last iteration multiplies its draw by 0 (ddpm.py:206)
+      // EXT 5: in-kernel jax.random.normal(key_j, xt.shape)[chain, ai] (frl_rng.h).  A draw is twelve branch-free micro-steps
+      // (frl_rng.h rng_micro); in the even k-steps of the FIRST hidden layer one micro-step follows each MFMA in program
+      // order, fenced by a scheduling barrier, so that the matrix pipe covers its ~14 VALU instructions.  (Letting the
+      // scheduler place a whole stage inside a k-step put the block in front of the MFMAs: measured, no gain.)  A network
+      // without a hidden layer draws up front.
+      uint32_t rk0 = 0, rk1 = 0;
+      RngDraw rd = {0u, 0u, 0u, 0u, 0.0f, 0.0f, 0.0f, 0.0f};
+      bool rused = false;
+      if constexpr (HAS_RNG || HAS_LN) {
+        if constexpr (HAS_RNG) { rk0 = a.rng_keys[2 * j]; rk1 = a.rng_keys[2 * j + 1]; }
+        rused = (HAS_RNG || a.rng_impl != FRL_RNG_NONE) && s_coef[j * COEF_STRIDE + 5] != 0.0f;   // c5 = 0: the last iteration multiplies its draw by 0 (ddpm.py:206)
+        if ((HAS_RNG && Lj < 2) || (HAS_LN && a.rng_impl != FRL_RNG_NONE)) {
           sfor<NRX>([&](auto RI) {
             constexpr int r = decltype(RI)::value;
             const int ai = G::rowr(r) + 4 * ls;
-            zr[r] = (used && valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai) : 0.0f;
+            zr[r] = (rused && valid && ai < a.A) ? rng_step_normal(a.rng_keys, a.rng_impl, j, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai) : 0.0f;
           });
         }
       }
+      auto rng_slot = [&](auto MI) __attribute__((always_inline)) {     // micro-step m of the step's NRX draws
+        constexpr int m = decltype(MI)::value, r = m / 12, mm = m % 12;
+        const int ai = G::rowr(r) + 4 * ls;
+        rng_micro<mm>(rd, rk0, rk1, a.rng_impl, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain) * a.A + ai);
+        if constexpr (mm == 11) zr[r] = (rused && valid && ai < a.A) ? rd.p : 0.0f;
+      };
       // ---------------- Dense_0 : P = tb[j] + W0x^T x + W0c^T cond ----------------------------------
       bias_init(P, crit ? s_ctb + ce * H : s_tb + j * H);
       if constexpr (EXT) {
         const float* sbias = a.state_bias;
-        if constexpr (EXT == 3) { if (crit) sbias = ct.ptrs[ce * CT_STRIDE + CT_ZS]; }
+        if constexpr (HAS_CRITIC && crit) sbias = uniform_ptr(ct.ptrs[ce * CT_STRIDE + CT_ZS]);
         if (sbias != nullptr) {
           // hoisted per-state slice of Dense_0 (the condition / observation rows, computed once per state by
           // frl_state_bias_kernel): every lane adds the row of ITS state; chains of one state share the cache lines
@@ -304,62 +331,83 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
       });
 
       // noise for this step and the first Dense_L operands: issued now, consumed after the hidden layers
-      if (EXT != 2 || a.rng_impl == FRL_RNG_NONE) {
+      if (!HAS_RNG && !(HAS_LN && a.rng_impl != FRL_RNG_NONE)) {
         sfor<NRX>([&](auto RI) {
           constexpr int r = decltype(RI)::value;
           const int ai = G::rowr(r) + 4 * ls;
           zr[r] = (a.noise != nullptr && !crit && valid && ai < a.A) ? a.noise[((long long)j * a.B + chain) * a.A + ai] : 0.0f;
         });
       }
-      if constexpr (EXT == 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
+      if constexpr (HAS_LN) { if (a.ws_ln != nullptr) ln_pass(P, s_ln); }
       constexpr int NLD = NK / 4;    // Dense_L: 16-byte loads, load q covers k-steps 4q .. 4q+3
       f32x4 rl[RINGL];
       sfor<RINGL - 1>([&](auto QI) { constexpr int q = decltype(QI)::value; rl[q] = ldw(rslc, voff_l, q * 1024); });
 
       // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P) ; P <- Q ----------------------------
-      for (int l = 1; l < Lj; ++l) {
+      auto hidden_layer = [&](const int l, auto RNG_T) __attribute__((always_inline)) {
+        constexpr bool with_rng = decltype(RNG_T)::value;
         // operands of this layer's first RING-1 k-steps are already in flight; the tail prefetches the next
         // layer's — after the last hidden layer that is the FIRST hidden layer of the next evaluation (next step /
         // critic member / tile)
         const float* wc = pick_ptr_rs(a.wh, l - 1);
         const float* wn = pick_ptr_rs(a.wh, (l + 1 < Lj) ? l : 0);
         const float* sb = s_bh + (l - 1) * H;
-        if constexpr (EXT == 3) {
-          if (crit) {
-            wc = ct.ptrs[ce * CT_STRIDE + CT_WH + l - 1];
+        if constexpr (HAS_CRITIC) {
+          if constexpr (crit) {
+            wc = uniform_ptr(ct.ptrs[ce * CT_STRIDE + CT_WH + l - 1]);
             sb = s_cbh + (ce * (ct.L - 1) + l - 1) * H;
-            if (l + 1 < Lj) wn = ct.ptrs[ce * CT_STRIDE + CT_WH + l];
+            if (l + 1 < Lj) wn = uniform_ptr(ct.ptrs[ce * CT_STRIDE + CT_WH + l]);
           }
-          if (l + 1 >= Lj) wn = critn ? ct.ptrs[(jn - a.NE) * CT_STRIDE + CT_WH] : a.wh[0];
+          if (l + 1 >= Lj) wn = critn ? uniform_ptr(ct.ptrs[cen * CT_STRIDE + CT_WH]) : a.wh[0];
         }
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wc, 0, H * ROWB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)wn, 0, H * ROWB, 0x00020000);
         bias_init(Q, sb);
-        // activations are computed two at a time on the even/odd register pair (2m, 2m+1) (an aligned pair, so
-        // the packed ops need no moves), one k-step before the first of the two is consumed
-        float bop, bn1, bn2 = 0.0f;
-        { const f32x2 y = act2(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
-        sfor<NK>([&](auto KI) {
-          constexpr int k = decltype(KI)::value;
-          if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
-          else hload(rsn, std::integral_constant<int, k + RING - 1>{});
-          if constexpr ((k & 1) == 1 && k + 2 < NK) {
-            const f32x2 y = act2(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
-            bn1 = y[0]; bn2 = y[1];
-          }
-          sfor<NG>([&](auto GI) {
-            constexpr int g = decltype(GI)::value;
-            const f32x4 aw = ring[k % RING][g];
-            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; Q[g * 4 + jj] = G::mfma(aw[jj], bop, Q[g * 4 + jj]); });
+        {
+          // activations are computed two at a time on the even/odd register pair (2m, 2m+1) (an aligned pair, so
+          // the packed ops need no moves), one k-step before the first of the two is consumed
+          float bop, bn1, bn2 = 0.0f;
+          { const f32x2 y = rs_act2<AC>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
+          sfor<NK>([&](auto KI) {
+            constexpr int k = decltype(KI)::value;
+            if constexpr (k + RING - 1 < NK) hload(rs, std::integral_constant<int, k + RING - 1>{});
+            else hload(rsn, std::integral_constant<int, k + RING - 1>{});
+            if constexpr ((k & 1) == 1 && k + 2 < NK) {
+              const f32x2 y = rs_act2<AC>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+              bn1 = y[0]; bn2 = y[1];
+            }
+            constexpr int NSLOT = 4 * NG;       // MFMAs per k-step
+            constexpr bool rng_here = with_rng && (k & 1) == 0 && k >= 2 && ((k - 2) / 2) * NSLOT < 12 * NRX;
+            sfor<NG>([&](auto GI) {
+              constexpr int g = decltype(GI)::value;
+              const f32x4 aw = ring[k % RING][g];
+              sfor<4>([&](auto JI) {
+                constexpr int jj = decltype(JI)::value;
+                Q[g * 4 + jj] = G::mfma(aw[jj], bop, Q[g * 4 + jj]);
+                if constexpr (rng_here) {
+                  constexpr int m = ((k - 2) / 2) * NSLOT + g * 4 + jj;
+                  if constexpr (m < 12 * NRX) rng_slot(std::integral_constant<int, m>{});
+                  if constexpr (g * 4 + jj > 0) __builtin_amdgcn_sched_barrier(0);     // MFMA i, then micro-step i: as written
+                }
+              });
+            });
+            // issue order inside the k-step: first MFMA, then the operand loads (RING-1 k-steps ahead)
+            if constexpr (!rng_here) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+              __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);   // VMEM reads
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one scheduling region per k-step (the group solver is superlinear)
+            bop = bn1; bn1 = bn2;
           });
-          // issue order inside the k-step: first MFMA, then the operand loads (RING-1 k-steps ahead)
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);   // VMEM reads
-          __builtin_amdgcn_sched_barrier(0);   // one scheduling region per k-step (the group solver is superlinear)
-          bop = bn1; bn1 = bn2;
-        });
+        }
         sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; P[b] = Q[b]; });
-        if constexpr (EXT == 2) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
+        if constexpr (HAS_LN) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
+      };
+      if constexpr (HAS_RNG) {
+        if (Lj > 1) hidden_layer(1, std::true_type{});
+        for (int l = 2; l < Lj; ++l) hidden_layer(l, std::false_type{});
+      } else {
+        for (int l = 1; l < Lj; ++l) hidden_layer(l, std::false_type{});
       }
 
       // next step's (or next tile's) first Dense_0 operands: in flight under Dense_L and the epilogue
@@ -370,13 +418,13 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
       sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = (crit ? s_cbl + ce * LAST_PAD : s_bl)[G::rowr(r) + 4 * ls]; });
       {
         float bop, bn1, bn2 = 0.0f;
-        { const f32x2 y = act2(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
+        { const f32x2 y = rs_act2<AC>(f32x2{P[0][0], P[0][1]}); bop = y[0]; bn1 = y[1]; }
         sfor<NK>([&](auto KI) {
           constexpr int k = decltype(KI)::value;
           if constexpr ((k & 3) == 0 && k / 4 + RINGL - 1 < NLD)
             rl[(k / 4 + RINGL - 1) % RINGL] = ldw(rslc, voff_l, (k / 4 + RINGL - 1) * 1024);
           if constexpr ((k & 1) == 1 && k + 2 < NK) {
-            const f32x2 y = act2(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
+            const f32x2 y = rs_act2<AC>(f32x2{P[(k + 1) / NR][(k + 1) % NR], P[(k + 2) / NR][(k + 2) % NR]});
             bn1 = y[0]; bn2 = y[1];
           }
           O = G::mfma(rl[(k / 4) % RINGL][k & 3], bop, O);
@@ -385,9 +433,10 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
       }
 
       // ---------------- epilogue: one reverse-diffusion / Euler step ---------------------------------
-      if constexpr (EXT == 3) {
+      if constexpr (HAS_CRITIC && crit) {
         // critic member ce: its scalar output is row 0 of the head = register 0 of lanes 0 .. 31; qs.min(axis=0), dql.py:155
-        if (crit) { qmin = (ce == 0) ? O[0] : fminf(qmin, O[0]); continue; }
+        qmin = (ce == 0) ? O[0] : fminf(qmin, O[0]);
+        return;
       }
       const float c0 = s_coef[jc * COEF_STRIDE + 0], c1 = s_coef[jc * COEF_STRIDE + 1];
       const float c2 = s_coef[jc * COEF_STRIDE + 2], c3 = s_coef[jc * COEF_STRIDE + 3];
@@ -442,9 +491,15 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
         }
         xs[r] = (EXT && a.mode == MODE_EVAL) ? ((valid && ai < a.AO) ? xn : 0.0f) : (in ? xn : 0.0f);
       });
+    };
+    for (int j = 0; j < a.NE; ++j) eval_body(std::false_type{}, std::integral_constant<int, ACT>{}, j, 0);
+    if constexpr (HAS_CRITIC) {
+      // EXT 4: the critic's activation is relu beside another sampler activation (QVPO / DACER: mish actor, relu critic)
+      constexpr int CACT = (EXT == 4) ? (int)FRL_ACT_RELU : ACT;
+      for (int e = 0; e < ct.E; ++e) eval_body(std::true_type{}, std::integral_constant<int, CACT>{}, 0, e);
     }
 
-    if (EXT != 3 || a.x0 != nullptr) {
+    if (!HAS_CRITIC || a.x0 != nullptr) {
       sfor<NRX>([&](auto RI) {
         constexpr int r = decltype(RI)::value;
         const int ai = G::rowr(r) + 4 * ls;
@@ -452,7 +507,7 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
       });
     }
 
-    if constexpr (EXT == 3) {
+    if constexpr (HAS_CRITIC) {
       // ---------------- best-of-N: argmax (or Gumbel-max categorical) over the state's particles, dql.py:156-161 ----------
       // A tile holds 32 / seg whole states of seg particles each (seg a power of two), or one 32-particle slice of a state.
       const int seg = ct.seg;
@@ -501,10 +556,10 @@ frl_sampler_rs_kernel(const KArgs a) {
 }
 
 // The same with the critic tail (EXT 3): sampler + scoring + selection in one launch.
-template <int TR, int H, int ACT, int NRX, int CKMAX>
+template <int TR, int H, int ACT, int NRX, int CKMAX, int CRELU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_rs_fused_kernel(const KArgs a, const CriticTab ct) {
-  sampler_rs_body<TR, H, ACT, NRX, CKMAX, 3>(a, ct);
+  sampler_rs_body<TR, H, ACT, NRX, CKMAX, 3 + CRELU>(a, ct);
 }
 
 // Two waves per SIMD, 256 registers per lane: the 16-chain geometry of the plain sampler (EXT 0: 249 registers, no
@@ -597,7 +652,8 @@ static int launch_inst(const KArgs& a, hipStream_t stream) {
     if (a.ws_ln == nullptr || a.ln_post_act == 0) { set_error("identity-activation build without a post-activation LayerNorm"); return FRL_EINVAL; }
     return launch_inst_v<TR, H, ACT, NRX, CKMAX, 2>(a, stream);
   }
-  if (a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 2>(a, stream);
+  if (a.ws_ln != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 2>(a, stream);
+  if (a.rng_impl != FRL_RNG_NONE) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 5>(a, stream);
   if constexpr (ACT != FRL_ACT_IDENTITY) {
     if (a.mode > MODE_CNF_EULER || a.state_bias != nullptr) return launch_inst_v<TR, H, ACT, NRX, CKMAX, 1>(a, stream);
     return launch_inst_v<TR, H, ACT, NRX, CKMAX, 0>(a, stream);
@@ -624,12 +680,17 @@ int launch_sampler_rs_act(const KArgs& a, hipStream_t stream) {
 }
 
 // sampler + critic scoring + selection in one launch (frl_sampler_select_fwd): the two 256-wide 32-chain geometries
+template <int TR, int H, int ACT, int NRX, int CKMAX, int CRELU>
+static int launch_fused_vr(const KArgs& a, const CriticTab& ct, hipStream_t stream) {
+  static thread_local size_t configured[16] = {0};
+  char tag[128];
+  snprintf(tag, sizeof(tag), "frl_sampler_rs_fused_kernel<TR %d, H %d, act %d, NRX %d, CKMAX %d, critic relu %d> [%d critics x %d layers]", TR, H, ACT, NRX, CKMAX, CRELU, ct.E, ct.L);
+  return launch_kern((const void*)frl_sampler_rs_fused_kernel<TR, H, ACT, NRX, CKMAX, CRELU>, tag, configured, TR, H, MAX_WAVES, a, stream, &ct);
+}
 template <int TR, int H, int ACT, int NRX, int CKMAX>
 static int launch_fused_v(const KArgs& a, const CriticTab& ct, hipStream_t stream) {
-  static thread_local size_t configured[16] = {0};
-  char tag[112];
-  snprintf(tag, sizeof(tag), "frl_sampler_rs_fused_kernel<TR %d, H %d, act %d, NRX %d, CKMAX %d> [%d critics x %d layers]", TR, H, ACT, NRX, CKMAX, ct.E, ct.L);
-  return launch_kern((const void*)frl_sampler_rs_fused_kernel<TR, H, ACT, NRX, CKMAX>, tag, configured, TR, H, MAX_WAVES, a, stream, &ct);
+  if constexpr (ACT != FRL_ACT_RELU) { if (ct.relu) return launch_fused_vr<TR, H, ACT, NRX, CKMAX, 1>(a, ct, stream); }
+  return launch_fused_vr<TR, H, ACT, NRX, CKMAX, 0>(a, ct, stream);
 }
 
 template <int ACT>
