@@ -291,8 +291,12 @@ frl_sampler_bf16_kernel(const KArgs a) {
       sfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; O[r] = s_bl[BF_ROWR(r) + 4 * ls]; });
       // this step's noise: requested at the head of Dense_L (16 MFMAs before its use) instead of in the epilogue, where the
       // wait for it also drained the stream's DMA pieces issued since (vector-memory results return in issue order).
-      // A/B'd and dropped in round 3: issuing the refill pieces one per 8 MFMAs instead of four at the chunk boundary
-      // (0.49 -> 0.57 ms: a DMA issued inside the MFMA / ds_read stream costs more than four behind the barrier).
+      // A/B'd and dropped in round 3 (same box, cfg2 mish, this kernel 0.534 ms): (1) issuing the refill pieces one per 8
+      // MFMAs instead of four at the chunk boundary — no gain; (2) a "ping-pong" build: every wave alternates PURE segments
+      // (16 MFMAs of a block | its activation), one s_barrier per segment, waves 4..7 one segment behind so that the two
+      // waves of a SIMD are always in opposite phases — 0.664 ms (relu 0.451 vs 0.363; pairing waves (w, w ^ 1) or
+      // (w, w ^ 2) instead: 0.94 ms, so w and w + 4 do share a SIMD): a wave alone issues its 16 dependent MFMAs + ds_reads
+      // at ~140 cycles each, and twice the barriers cost more than the phase overlap returns.
       float zn[NRX];
       {
         const char* sl = next_chunk() + lane16;
