@@ -11,5 +11,9 @@ timeout -k 10 300 python bench.py --workload cfg4 --no-cpu-baseline --steps 10 -
 timeout -k 10 200 python bench.py --workload cfg5 --no-cpu-baseline > gpurun_out/final/cfg5_f32.json 2>/dev/null || exit 7
 timeout -k 10 200 python bench.py --workload cfg5 --dtype bf16 --no-cpu-baseline > gpurun_out/final/cfg5_bf16.json 2>/dev/null || exit 8
 timeout -k 10 200 python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/final/cfg2_bf16.json 2>/dev/null || exit 9
-scripts/prof.sh final > gpurun_out/final/prof.log 2>&1 || exit 10
+timeout -k 10 200 python bench.py --rng partitionable --no-cpu-baseline > gpurun_out/final/cfg2_keyed.json 2>/dev/null || exit 11
+timeout -k 10 300 python bench.py --workload cfg4 --rng partitionable --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_keyed.json 2>/dev/null || exit 12
+timeout -k 10 300 python bench.py --workload cfg4 --select fused --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_select_fused.json 2>/dev/null || exit 13
+timeout -k 10 300 python bench.py --workload cfg4 --select separate --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_select_separate.json 2>/dev/null || exit 14
+timeout -k 10 200 bench/native_bench > gpurun_out/final/native_cfg2.json 2>/dev/null || exit 15
 echo done
