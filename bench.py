@@ -410,6 +410,9 @@ def main():
                     help="multi-particle workloads: a step is sample + critic scoring + best-of-N selection (jit_sample_and_select / "
                          "jit_sample_actions) with an Ensemblize(ScalarCritic(MLP 256x2 relu)) x 2 critic; fused = one launch "
                          "(frl_sampler_select_fwd), separate = frl_sampler_fwd + frl_critic_select")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph (torch.cuda.CUDAGraph) after the warm-up and time its replays: what a "
+                         "launch-bound acting loop (small --batch) pays per step without the host-side enqueue of 3..8 kernels")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank owns the workload's per-GPU batch; strong: the workload's TOTAL batch (SURVEY 8(d): cfg4 = "
                          "65536 states x 64 particles, cfg3 = 8388608 chains; others: the per-GPU batch) is split over the ranks by state index "
@@ -531,9 +534,28 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    run = step
+    if args.graph:
+        if world > 1 or vjp:
+            ap.error("--graph: single-GPU forward workloads")
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            x0_graph = step()
+
+        def run():
+            graph.replay()
+            return x0_graph
+        run()
+        fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x0 = step()
+        x0 = run()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -568,7 +590,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}" + (f" [strong scaling: {job_chains} chains in total, {B} on rank 0]" if total_chains is not None else ""), "chains_per_gpu": B, "T": T,
-                       "chains_per_s": value / T, "prepare": "cached across calls" if args.cache_prepare else "every call", "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
+                       "chains_per_s": value / T, "prepare": "cached across calls" if args.cache_prepare else "every call", "noise": "caller tensor (T, B, A)" if args.rng == "none" else f"in-kernel threefry ({args.rng})", "launch": "HIP graph replay" if args.graph else "eager", "collective": "none" if world == 1 or args.no_gather else ("all_reduce(flat grads)" if vjp else "all_gather(x0)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes/launch",

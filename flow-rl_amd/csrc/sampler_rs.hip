@@ -92,7 +92,12 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
   }
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
   for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
-  float* s_ln = s_coef + a.NE * COEF_STRIDE;          // EXT 2, LayerNorm backbones only: [L][2][H] scale | bias rows
+  // EXT builds with the per-state hoist and whole tiles per state (particles a multiple of TR): the tile's ONE row of hoisted
+  // condition features, copied per wave into LDS at the head of the tile — every step then reads it back at LDS latency
+  // instead of paying an L2 round trip in front of Dense_0's MFMAs (cfg4: 32 x 16-byte loads per lane and step)
+  const bool zrow_lds = EXT != 0 && a.state_bias != nullptr && (a.particles % TR) == 0;
+  float* s_zrow = s_coef + a.NE * COEF_STRIDE;
+  float* s_ln = s_zrow + (zrow_lds ? nw * H : 0);     // EXT 2, LayerNorm backbones only: [L][2][H] scale | bias rows
   if constexpr (HAS_LN) {
     if (a.ws_ln != nullptr)
       for (int idx = tid; idx < a.L * 2 * H; idx += blockDim.x) s_ln[idx] = a.ws_ln[idx];
@@ -244,6 +249,13 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
       cb[c] = (valid && k < a.C) ? a.cond[state * a.C + k] : 0.0f;
     });
 
+    if constexpr (EXT != 0) {
+      if (zrow_lds) {      // wave-private: DS operations of one wave execute in order, no barrier
+        for (int o = lane * 4; o < H; o += 256)
+          *(f32x4*)(s_zrow + wave * H + o) = *(const f32x4*)(a.state_bias + state * H + o);
+      }
+    }
+
     // EXT only — dpm++2m: previous x0_hat (scan carry, continuous_ddpm.py:219); dpm2: the step's original xt
     float aux[EXT ? NRX : 1];
     sfor<(EXT ? NRX : 1)>([&](auto RI) { aux[decltype(RI)::value] = 0.0f; });
@@ -305,15 +317,18 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
         if (sbias != nullptr) {
           // hoisted per-state slice of Dense_0 (the condition / observation rows, computed once per state by
           // frl_state_bias_kernel): every lane adds the row of ITS state; chains of one state share the cache lines
-          const float* zrow = sbias + (valid ? state : 0) * H;
-          sfor<NG>([&](auto GI) {
-            constexpr int g = decltype(GI)::value;
-            sfor<NR>([&](auto RI) {
-              constexpr int r = decltype(RI)::value;
-              const f32x4 bv = *(const f32x4*)(zrow + g * GW + 4 * (G::rowr(r) + 4 * ls));
-              sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] += bv[jj]; });
+          auto add_row = [&](const float* zrow) __attribute__((always_inline)) {
+            sfor<NG>([&](auto GI) {
+              constexpr int g = decltype(GI)::value;
+              sfor<NR>([&](auto RI) {
+                constexpr int r = decltype(RI)::value;
+                const f32x4 bv = *(const f32x4*)(zrow + g * GW + 4 * (G::rowr(r) + 4 * ls));
+                sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] += bv[jj]; });
+              });
             });
-          });
+          };
+          if (zrow_lds && !crit) add_row(s_zrow + wave * H);
+          else add_row(sbias + (valid ? state : 0) * H);
         }
       }
       sfor<N0>([&](auto NI) {
@@ -600,6 +615,7 @@ static int launch_kern(const void* kern, const char* tag, size_t* configured, in
   const int grid = (int)(nwg < ncu ? nwg : ncu);
   const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE +
                                       (a.ws_ln != nullptr ? (size_t)a.L * 2 * H : 0) +
+                                      ((a.state_bias != nullptr && a.particles % TR == 0) ? (size_t)nw * H : 0) +
                                       (ct != nullptr ? (size_t)ct->E * ((size_t)ct->L * H + LAST_PAD) : 0));
   if (lds > 160 * 1024) { set_error("sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
   int dev = 0;
