@@ -104,8 +104,14 @@ static int launch_f32_network(const KArgs& a, int act, int tile_policy, hipStrea
   }
 }
 
-// residual backbones (ResidualMLP / Simba): the throughput build of csrc/sampler_res.hip for every batch size
-static int launch_res_network(const KArgs& a, const ResArgs& ra, int act, hipStream_t stream) {
+// residual backbones (ResidualMLP / Simba), csrc/sampler_res.hip: four waves per tile (latency build) while its rounds cost
+// less than the throughput build's — one tile per CU against four, at about a quarter of the time per round
+static int launch_res_network(const KArgs& a, const ResArgs& ra_in, int act, int tile_policy, hipStream_t stream) {
+  ResArgs ra = ra_in;
+  const long long ntiles = (a.B + 31) / 32, cus = device_cus();
+  const long long r_lat = (ntiles + cus - 1) / cus, r_thr = (ntiles + 4 * cus - 1) / (4 * cus);
+  ra.split = (tile_policy == FRL_TILE_LATENCY || tile_policy == FRL_TILE_LATENCY_32 ||
+              (tile_policy == FRL_TILE_AUTO && r_lat <= 3 * r_thr && res_lds_bytes(a.NE, ra.n_blocks, 4) <= 160 * 1024)) ? 4 : 1;
   switch (act) {
     case FRL_ACT_MISH: return launch_sampler_res_act<FRL_ACT_MISH>(a, ra, stream);
     case FRL_ACT_SILU: return launch_sampler_res_act<FRL_ACT_SILU>(a, ra, stream);
@@ -191,8 +197,8 @@ static int validate_desc(const FrlDesc* d) {
       if (d->hidden[l] != 256) { set_error("residual backbones: hidden widths must all be 256 (hidden[%d] = %d)", l, d->hidden[l]); return FRL_EUNSUPPORTED; }
     if (d->layer_norm == FRL_LN_POST_ACT) { set_error("residual backbones: layer_norm is 0 or FRL_LN_PRE_ACT (ResidualLinear normalises its input)"); return FRL_EINVAL; }
     if (d->x_dim > 24) { set_error("residual backbones: x_dim %d > 24", d->x_dim); return FRL_EUNSUPPORTED; }
-    if (d->tile_policy != FRL_TILE_AUTO && d->tile_policy != FRL_TILE_THROUGHPUT) { set_error("residual backbones: no latency build (tile_policy %d)", d->tile_policy); return FRL_EUNSUPPORTED; }
-    if (res_lds_bytes((d->solver == FRL_SOLVER_DPM2 ? 2 : 1) * d->steps, d->n_hidden) > 160 * 1024) { set_error("residual backbones: %d steps x %d blocks exceed the LDS tables", d->steps, d->n_hidden); return FRL_EUNSUPPORTED; }
+    if (d->tile_policy == FRL_TILE_LATENCY_16) { set_error("residual backbones: the latency build runs 32-chain tiles (tile_policy LATENCY / LATENCY_32)"); return FRL_EUNSUPPORTED; }
+    if (res_lds_bytes((d->solver == FRL_SOLVER_DPM2 ? 2 : 1) * d->steps, d->n_hidden, (d->tile_policy == FRL_TILE_LATENCY || d->tile_policy == FRL_TILE_LATENCY_32) ? 4 : 1) > 160 * 1024) { set_error("residual backbones: %d steps x %d blocks exceed the LDS tables", d->steps, d->n_hidden); return FRL_EUNSUPPORTED; }
     return FRL_OK;
   }
   if (d->dtype == FRL_DTYPE_BF16) {
@@ -459,7 +465,7 @@ static int sampler_run_impl(const FrlDesc* desc, const FrlParams* params, const 
   }
   a.wl_raw = params->kernel[pl.L];
   if (fused != nullptr) return launch_fused_network(a, *fused, desc->act, (hipStream_t)hip_stream);
-  if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, (hipStream_t)hip_stream);
+  if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
   return launch_f32_network(a, desc->act, desc->tile_policy, (hipStream_t)hip_stream);
 }
 
@@ -1104,7 +1110,7 @@ int frl_net_eval(const FrlDesc* desc, const FrlParams* params, const FrlEvalBufs
   a.mode = MODE_EVAL;
   a.XR = pl.XR; a.AR = pl.AR; a.CK = pl.CK; a.merged = pl.merged; a.n_l0 = pl.n_l0; a.NS = pl.NS;
   a.wl_raw = params->kernel[pl.L];
-  if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, stream);
+  if (desc->backbone != FRL_BACKBONE_MLP) return launch_res_network(a, ra, desc->act, desc->tile_policy, stream);
   return launch_f32_network(a, desc->act, desc->tile_policy, stream);
 }
 

@@ -227,13 +227,16 @@ struct CriticTab {
 // around a residual, optionally behind a LayerNorm; kernels read in place.
 struct ResArgs {
   int n_blocks, ln, final_ln, final_act;      // final_act: ResidualMLP's act before Dense_1; final_ln: Simba's LayerNorm there
+  int split;                                  // 1: one wave per 32-chain tile (throughput); 4: the latency build, four waves per tile
   const float* w1[FRL_MAX_HIDDEN]; const float* b1[FRL_MAX_HIDDEN];
   const float* w2[FRL_MAX_HIDDEN]; const float* b2[FRL_MAX_HIDDEN];
   const float* ln_scale[FRL_MAX_HIDDEN]; const float* ln_bias[FRL_MAX_HIDDEN];
   const float* fln_scale; const float* fln_bias;
 };
-inline size_t res_lds_bytes(int NE, int n_blocks) {
-  return sizeof(float) * ((size_t)NE * 256 + LAST_PAD + (size_t)NE * COEF_STRIDE + (size_t)n_blocks * (1024 + 3 * 256) + 2 * 256);
+constexpr int RES_RED_FLOATS = 4 * 64 * 64;   // latency build: four waves' partial sums of HALF of x (64 registers x 64 lanes each)
+inline size_t res_lds_bytes(int NE, int n_blocks, int split = 1) {
+  return sizeof(float) * ((size_t)NE * 256 + LAST_PAD + (size_t)NE * COEF_STRIDE + (size_t)n_blocks * (1024 + 3 * 256) + 2 * 256 +
+                          (split > 1 ? (size_t)RES_RED_FLOATS : 0));
 }
 
 // Arguments of the prepare kernel.

@@ -17,6 +17,14 @@
 // layer's row map (row = GW g + j + 4 ROWR(r) + 16 s).  One operand ring serves both: the tail of each GEMM prefetches the
 // head of the next (next group / next block / block 0 of the next evaluation), so no phase starts cold.
 // Condition rows of Dense_0 are always hoisted per state (frl_state_bias_kernel): the register budget goes to the blocks.
+//
+// Latency build (SPLIT = 4, round 3): acting with a Simba / ResidualMLP policy at batch 1 .. a few thousand chains leaves most
+// SIMDs idle in the one-wave-per-tile build, and a block is a serial chain of 8192 64-cycle MFMAs per wave (0.22 ms per
+// block and step).  The eight expansion groups of a block are independent given LayerNorm(x) and their contributions to x
+// add up, so the FOUR waves of a workgroup share one tile: every wave holds the whole x (Dense_0, the LayerNorms, the head
+// and the update rule are computed redundantly, bit-identically, in all four), takes two of the eight groups, and the
+// partial sums (wave 0's includes x + b2) are exchanged through LDS in two halves and added in wave order by everyone.
+// Fixed order: deterministic; the rounding differs from the throughput build's (one wave adds the groups in sequence).
 #include "frl_device.h"
 #include "frl_rng.h"
 
@@ -29,7 +37,7 @@ __device__ __forceinline__ const float* pick_ptr8(const float* const (&arr)[FRL_
   return p;
 }
 
-template <int ACT, int NRX>
+template <int ACT, int NRX, int SPLIT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
   typedef Geo<32> G;
@@ -61,6 +69,9 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
   float* s_coef = s_bl + LAST_PAD;                    // [NE][8]
   float* s_blk = s_coef + a.NE * COEF_STRIDE;         // [nblk][BLK]
   float* s_fln = s_blk + nblk * BLK;                  // [2][H] final LayerNorm (Simba)
+  float* s_red = s_fln + 2 * H;                       // SPLIT > 1: [4 waves][64 registers][64 lanes] partial sums of half of x
+  constexpr int GPW = NGM / SPLIT;                    // expansion groups per wave
+  const int g_lo = (SPLIT > 1) ? wave * GPW : 0, g_hi = g_lo + GPW;
   for (int idx = tid; idx < a.NE * H; idx += blockDim.x) s_tb[idx] = a.ws_tb[idx];
   if (tid < LAST_PAD) s_bl[tid] = a.ws_blp[tid];
   for (int idx = tid; idx < a.NE * COEF_STRIDE; idx += blockDim.x) s_coef[idx] = a.ws_coef[idx];
@@ -152,9 +163,9 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
 
   // weight operands never depend on the data: the first ring entries of Dense_0 and of block 0 stay one phase ahead
   sfor<(NRX < RING - 1 ? NRX : RING - 1)>([&](auto NI) { l0load(NI); });
-  sfor<RING - 1>([&](auto KI) { load1(rs_first, 0, KI); });
+  sfor<RING - 1>([&](auto KI) { load1(rs_first, g_lo, KI); });
 
-  for (int wt = blockIdx.x * nw + wave; wt < n_wt; wt += gridDim.x * nw) {
+  for (int wt = (SPLIT > 1) ? (int)blockIdx.x : (int)(blockIdx.x * nw + wave); wt < n_wt; wt += (SPLIT > 1) ? (int)gridDim.x : (int)(gridDim.x * nw)) {
     const long long chain = (long long)wt * TR + li;
     const bool valid = chain < a.B;
     const long long state = (a.particles == 1) ? chain : chain / a.particles;
@@ -227,16 +238,20 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
         const __amdgpu_buffer_rsrc_t rs1n = __builtin_amdgcn_make_buffer_rsrc((void*)pick_ptr8(ra.w1, (i + 1 < nblk) ? i + 1 : 0), 0, H * ROWB1, 0x00020000);
         sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; Xn[b] = P[b]; });
         if (ra.ln) ln_pass(Xn, sb + M + H);
-        // x + b2: the residual and Dense_1's bias are the accumulator's starting value
-        sfor<NG>([&](auto GI) {
-          constexpr int g = decltype(GI)::value;
-          sfor<NR>([&](auto RI) {
-            constexpr int r = decltype(RI)::value;
-            const f32x4 bv = *(const f32x4*)(sb + M + g * GW + 4 * (G::rowr(r) + 4 * ls));
-            sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] += bv[jj]; });
+        // x + b2: the residual and Dense_1's bias are the accumulator's starting value (SPLIT: wave 0's; the others start at 0)
+        if (SPLIT == 1 || wave == 0) {
+          sfor<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            sfor<NR>([&](auto RI) {
+              constexpr int r = decltype(RI)::value;
+              const f32x4 bv = *(const f32x4*)(sb + M + g * GW + 4 * (G::rowr(r) + 4 * ls));
+              sfor<4>([&](auto JI) { constexpr int jj = decltype(JI)::value; P[g * 4 + jj][r] += bv[jj]; });
+            });
           });
-        });
-        for (int g = 0; g < NGM; ++g) {
+        } else {
+          sfor<NB>([&](auto BI) { constexpr int b = decltype(BI)::value; sfor<NR>([&](auto RI) { P[b][decltype(RI)::value] = 0.0f; }); });
+        }
+        for (int g = g_lo; g < g_hi; ++g) {
           acc_t Y[4];
           sfor<NR>([&](auto RI) {
             constexpr int r = decltype(RI)::value;
@@ -256,8 +271,8 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
             __builtin_amdgcn_sched_barrier(0);
           });
           // ---- x += W2[g, :]^T act(Y) ----
-          const int gn = (g + 1 < NGM) ? g + 1 : 0;
-          const __amdgpu_buffer_rsrc_t rsn = (g + 1 < NGM) ? rs1 : rs1n;
+          const int gn = (g + 1 < g_hi) ? g + 1 : g_lo;
+          const __amdgpu_buffer_rsrc_t rsn = (g + 1 < g_hi) ? rs1 : rs1n;
           float bop, bn1, bn2 = 0.0f;
           { const f32x2 y = act_fn2<ACT>(f32x2{Y[0][0], Y[0][1]}); bop = y[0]; bn1 = y[1]; }
           sfor<NK2>([&](auto KI) {
@@ -277,6 +292,26 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
             __builtin_amdgcn_sched_group_barrier(0x020, (k + RING - 1 < NK2) ? NG : 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             bop = bn1; bn1 = bn2;
+          });
+        }
+        if constexpr (SPLIT > 1) {
+          // x <- sum over the four waves' partial sums, in wave order, in every wave: two halves of 4 feature blocks each
+          sfor<2>([&](auto HI) {
+            constexpr int hb = 4 * decltype(HI)::value;
+            sfor<4>([&](auto BI) {
+              constexpr int b = decltype(BI)::value;
+              sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; s_red[((wave * 64) + b * NR + r) * 64 + lane] = P[hb + b][r]; });
+            });
+            __syncthreads();
+            sfor<4>([&](auto BI) {
+              constexpr int b = decltype(BI)::value;
+              sfor<NR>([&](auto RI) {
+                constexpr int r = decltype(RI)::value;
+                const int o = (b * NR + r) * 64 + lane;
+                P[hb + b][r] = ((s_red[o] + s_red[64 * 64 + o]) + s_red[2 * 64 * 64 + o]) + s_red[3 * 64 * 64 + o];
+              });
+            });
+            __syncthreads();
           });
         }
       }
@@ -317,7 +352,7 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
         const int ai = G::rowr(r) + 4 * ls;
         const bool in = valid && ai < a.A;
         const float eps = O[r], xt = xs[r];
-        if (a.xt_hist != nullptr && in && c6 == 0.0f) {
+        if (a.xt_hist != nullptr && in && c6 == 0.0f && (SPLIT == 1 || wave == 0)) {
           const int jh = (a.mode == MODE_CDDPM_DPM2) ? j >> 1 : j;
           const long long o = ((long long)jh * a.B + chain) * a.A + ai;
           a.xt_hist[o] = xt;
@@ -366,30 +401,31 @@ frl_sampler_res_kernel(const KArgs a, const ResArgs ra) {
     sfor<NRX>([&](auto RI) {
       constexpr int r = decltype(RI)::value;
       const int ai = G::rowr(r) + 4 * ls;
-      if (valid && ai < a.AO) a.x0[chain * a.AO + ai] = xs[r];
+      if (valid && ai < a.AO && (SPLIT == 1 || wave == 0)) a.x0[chain * a.AO + ai] = xs[r];
     });
   }
 }
 
 // ---- launcher -----------------------------------------------------------------------------------------------------
-template <int ACT, int NRX>
+template <int ACT, int NRX, int SPLIT>
 static int launch_res_inst(const KArgs& a, const ResArgs& ra, hipStream_t stream) {
-  auto kern = frl_sampler_res_kernel<ACT, NRX>;
+  auto kern = frl_sampler_res_kernel<ACT, NRX, SPLIT>;
   const int ncu = device_cus();
   const long long n_wt = (a.B + 31) / 32;
   long long per_cu = (n_wt + ncu - 1) / ncu;
   int nw = (int)(per_cu < 1 ? 1 : (per_cu > MAX_WAVES ? MAX_WAVES : per_cu));
   if (nw == 3) nw = 4;
   long long nwg = (n_wt + nw - 1) / nw;
-  const int grid = (int)(nwg < ncu ? nwg : ncu);
-  const size_t lds = res_lds_bytes(a.NE, ra.n_blocks);
+  int grid = (int)(nwg < ncu ? nwg : ncu);
+  if (SPLIT > 1) { nw = 4; grid = (int)(n_wt < ncu ? n_wt : ncu); }     // one tile at a time per workgroup of four waves (= per CU)
+  const size_t lds = res_lds_bytes(a.NE, ra.n_blocks, SPLIT);
   if (lds > 160 * 1024) { set_error("residual sampler: %d evaluations x %d blocks need %zu B of LDS (> 160 KiB)", a.NE, ra.n_blocks, lds); return FRL_EUNSUPPORTED; }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, stream, a, ra);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("residual sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
-  note_kernel("frl_sampler_res_kernel<act %d, NRX %d> [grid %d x %d waves]", ACT, NRX, grid, nw);
+  note_kernel("frl_sampler_res_kernel<act %d, NRX %d, split %d> [grid %d x %d waves]", ACT, NRX, SPLIT, grid, nw);
   return FRL_OK;
 }
 
@@ -397,8 +433,13 @@ template <int ACT>
 int launch_sampler_res_act(const KArgs& a, const ResArgs& ra, hipStream_t stream) {
   if (a.H != 256 || a.TR != 32 || a.C != 0 || a.CK != 0) { set_error("residual sampler: 256-wide blocks with hoisted condition rows only"); return FRL_EUNSUPPORTED; }
   if (ra.n_blocks < 1 || ra.n_blocks > FRL_MAX_HIDDEN) { set_error("residual sampler: %d blocks", ra.n_blocks); return FRL_EINVAL; }
-  if (a.AR <= 4) return launch_res_inst<ACT, 4>(a, ra, stream);
-  if (a.AR <= 12) return launch_res_inst<ACT, 12>(a, ra, stream);
+  if (ra.split > 1) {
+    if (a.AR <= 4) return launch_res_inst<ACT, 4, 4>(a, ra, stream);
+    if (a.AR <= 12) return launch_res_inst<ACT, 12, 4>(a, ra, stream);
+  } else {
+    if (a.AR <= 4) return launch_res_inst<ACT, 4, 1>(a, ra, stream);
+    if (a.AR <= 12) return launch_res_inst<ACT, 12, 1>(a, ra, stream);
+  }
   set_error("residual sampler: x_dim %d exceeds the compiled operand budget (x_dim <= 24)", a.A);
   return FRL_EUNSUPPORTED;
 }

@@ -28,12 +28,19 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("build", ["throughput", "latency"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
-def test_residual_sampler(case):
+def test_residual_sampler(case, build):
+    """Both builds of csrc/sampler_res.hip: one wave per 32-chain tile, and the latency build (four waves per tile, the
+    expansion groups of a block split over them, partial sums added in wave order)."""
+    import dataclasses
+    import flowrl_hip as fh
+    case = dataclasses.replace(case, tile=build)
     params, xT, cond, noise = H.make_inputs(case)
     ref = H.oracle_run(case, params, xT, cond, noise, dtype=np.float64)
     model = H.product_model(case, params)
     x0, xh, eh = H.product_run(case, model, xT, cond, noise)
+    assert ("split 4" if build == "latency" else "split 1") in fh.last_kernels()
     e_first = H.rel_err(eh[0], ref[2][0])
     es, rs, ee = H.float32_chain_deviation(case, params, xT, cond, noise, ref)
     e0, ex = H.rel_err(x0, ref[0]), H.rel_err(xh, ref[1])
@@ -41,6 +48,26 @@ def test_residual_sampler(case):
     assert x0.shape == ref[0].shape and e_first <= 1e-5
     tol = max(1e-5, 4.0 * es)
     assert e0 <= tol and ex <= tol and H.rel_err(eh, ref[2]) <= max(1e-5, 4.0 * ee)
+    H.record_margin("residual", case.name, build, first_eval=e_first, x0=e0, bar=tol)
+
+
+def test_residual_auto_policy_picks_the_latency_build_for_acting_batches():
+    """tile_policy auto: a Simba / ResidualMLP policy acting at batch 1 .. a few thousand chains runs four waves per tile;
+    a throughput-sized batch keeps one wave per tile.  Two calls of the latency build are bit-identical (fixed-order sums)."""
+    import torch
+    import flowrl_hip as fh
+    small = CASES[0]
+    params, xT, cond, noise = H.make_inputs(small)
+    model = H.product_model(small, params)
+    a = H.product_run(small, model, xT, cond, noise)
+    assert "split 4" in fh.last_kernels()
+    b = H.product_run(small, model, xT, cond, noise)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    big = H.Case("resnet-throughput-size", "ddpm", A=3, S=11, T=2, B=140000, hidden=(256,), backbone="residual", ln=True, seed=12)
+    params, xT, cond, noise = H.make_inputs(big)
+    H.product_run(big, H.product_model(big, params), xT, cond, noise, history=False)
+    assert "split 1" in fh.last_kernels()
 
 
 def test_residual_in_kernel_rng_and_determinism():
@@ -79,7 +106,7 @@ def test_residual_net_eval_per_sample_time():
 
 
 def test_residual_refusals():
-    """Loud refusals: bf16, latency builds, the VJP, unequal block widths."""
+    """Loud refusals: bf16, 16-chain latency tiles, the chain VJP, unequal block widths."""
     import torch
     from flowrl_hip import _lib
     case = CASES[0]
@@ -89,7 +116,7 @@ def test_residual_refusals():
     with pytest.raises(_lib.FlowRLHipUnsupported):
         model.sample(None, x, c, noise=nz, compute_dtype="bf16")
     with pytest.raises(_lib.FlowRLHipUnsupported):
-        model.sample(None, x, c, noise=nz, tile_policy="latency")
+        model.sample(None, x, c, noise=nz, tile_policy="latency16")
     with pytest.raises(_lib.FlowRLHipUnsupported):
         model.sample(None, x, c, True, noise=nz, history=True, keep_for_vjp=True, params=model.params)
 
