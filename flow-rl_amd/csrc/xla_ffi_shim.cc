@@ -281,7 +281,69 @@ ffi::Error FrlSamplerBwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, 
   return FromRc(frl_sampler_bwd(&d, &p, &s, &b, *ws, need, (void*)stream));
 }
 
+// FrlSamplerSelectFwd: jit_sample_and_select (dql.py:130-162) / jit_sample_actions (qvpo.py:21-44) after the caller's draws, ONE
+// launch (frl_sampler_select_fwd).  Operands: FrlSamplerFwd's (0 xT (n_states * particles, A), 1 obs (n_states, S) — the
+// sampler's condition AND the critic's observation, 2 noise, 3..19, the sampler's layers), then at the END: gumbel
+// (n_states, particles) f32 or empty, and the critic's stacked leaves (kernel_i (E, in, out), bias_i (E, out)) for
+// i = 0..Lc (backbone Dense_0..Dense_{Lc-1}, then the head).  Attributes: FrlSamplerFwd's + critic_layers (Lc), ensemble,
+// critic_act, inv_temperature (1 / (1e-6 + T); used with gumbel), want_q.  Results: best_action (n_states, A) f32,
+// best_idx (n_states,) s32, then q (n_states, particles) f32 when want_q = 1.
+ffi::Error FrlSamplerSelectFwdImpl(hipStream_t stream, ffi::ScratchAllocator scratch, ffi::RemainingArgs args,
+                                   ffi::RemainingRets rets, ffi::Dictionary attrs) {
+  const int32_t lc = AttrOr<int32_t>(attrs, "critic_layers", 0);
+  if (lc < 1 || lc > FRL_MAX_HIDDEN) return Invalid("critic_layers outside [1, FRL_MAX_HIDDEN]");
+  const size_t trailing = 1 + 2 * (size_t)(lc + 1);
+  if (args.size() < kFixedOperands + 4 + trailing) return Invalid("FrlSamplerSelectFwd: too few operands");
+  FrlDesc d; FrlParams p; FrlSchedule s;
+  FrlFwdBufs b;
+  std::memset(&b, 0, sizeof(b));
+  int64_t x_dim = 0, cond_last = 0;
+  if (!Operand<float>(args, 0, ffi::DataType::F32, &b.xT, &x_dim) || !Operand<float>(args, 1, ffi::DataType::F32, &b.cond, &cond_last) ||
+      !Operand<float>(args, 2, ffi::DataType::F32, &b.noise))
+    return Invalid("xT / obs / noise must be f32");
+  if (b.cond == nullptr) cond_last = 0;
+  if (ffi::Error e = Marshal(args, attrs, x_dim, cond_last, &d, &p, &s, trailing); e.failure()) return e;
+  d.want_history = 0;
+  FrlCriticDesc cd;
+  FrlCriticParams cp;
+  FrlSelectBufs sb;
+  std::memset(&cd, 0, sizeof(cd)); std::memset(&cp, 0, sizeof(cp)); std::memset(&sb, 0, sizeof(sb));
+  cd.abi_version = FRL_ABI_VERSION;
+  cd.n_states = d.n_states; cd.particles = d.particles;
+  cd.obs_dim = (int32_t)cond_last; cd.act_dim = d.x_dim; cd.n_hidden = lc;
+  cd.act = AttrOr<int32_t>(attrs, "critic_act", d.act);
+  cd.ensemble = AttrOr<int32_t>(attrs, "ensemble", 2);
+  const size_t base = args.size() - trailing;
+  if (!Operand<float>(args, base, ffi::DataType::F32, &sb.gumbel)) return Invalid("gumbel must be f32 (or empty)");
+  sb.inv_temperature = AttrOr<float>(attrs, "inv_temperature", 1.0f);
+  for (int l = 0; l <= lc; ++l) {
+    int64_t width = 0;
+    if (!Operand<float>(args, base + 1 + 2 * l, ffi::DataType::F32, &cp.kernel[l], &width) ||
+        !Operand<float>(args, base + 2 + 2 * l, ffi::DataType::F32, &cp.bias[l]))
+      return Invalid("critic operands must be f32");
+    if (l < lc) cd.hidden[l] = (int32_t)width;
+  }
+  sb.obs = b.cond;
+  size_t out = 0;
+  if (!Output<float>(rets, out++, ffi::DataType::F32, &sb.best_action) || !Output<int32_t>(rets, out++, ffi::DataType::S32, &sb.best_idx))
+    return Invalid("results: best_action (n_states, A) f32, best_idx (n_states,) s32");
+  if (AttrOr<int32_t>(attrs, "want_q", 0) && !Output<float>(rets, out++, ffi::DataType::F32, &sb.q)) return Invalid("want_q = 1: result q (n_states, particles) f32");
+  const size_t need = frl_sampler_select_workspace_bytes(&d, &cd);
+  if (need == 0) return FromRc(frl_sampler_select_fwd(&d, &p, &s, &b, &cd, &cp, &sb, nullptr, 0, (void*)stream));   // says why
+  auto ws = scratch.Allocate(need, 256);
+  if (!ws.has_value()) return ffi::Error(ffi::ErrorCode::kResourceExhausted, "scratch allocation failed");
+  return FromRc(frl_sampler_select_fwd(&d, &p, &s, &b, &cd, &cp, &sb, *ws, need, (void*)stream));
+}
+
 }  // namespace
+
+XLA_FFI_DEFINE_HANDLER_SYMBOL(FrlSamplerSelectFwd, FrlSamplerSelectFwdImpl,
+                              ffi::Ffi::Bind()
+                                  .Ctx<ffi::PlatformStream<hipStream_t>>()
+                                  .Ctx<ffi::ScratchAllocator>()
+                                  .RemainingArgs()
+                                  .RemainingRets()
+                                  .Attrs());
 
 XLA_FFI_DEFINE_HANDLER_SYMBOL(FrlSamplerFwd, FrlSamplerFwdImpl,
                               ffi::Ffi::Bind()
