@@ -77,7 +77,7 @@ def build_model(w, device, seed=0):
     elif w.get("backbone") == "simba":
         mlp = fh.Simba(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"])
     else:
-        mlp = fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"])
+        mlp = fh.MLP(hidden_dims=w["hidden"], output_dim=w["A"], activation=w["act"], layer_norm=bool(w.get("ln")))
     ce = fh.MLP(hidden_dims=[128, 128], activation=w["act"]) if w["cond_embed"] else None
     inputs = (np.ones((1, w["A"])), np.zeros((1, 1)), np.ones((1, w["S"])))
     if w["kind"] == "cnf":
@@ -109,9 +109,14 @@ def sample(model, w, xT, cond, noise):
     if w["kind"] == "cnf":
         return model.sample(None, xT, cond, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), cache_prepare=w.get("cache_prepare", False))[1]
     if w.get("rng", "none") != "none":
-        from flowrl_hip import random as fr
-        key = fr.PRNGKey(0, xT.device)
-        return model.sample(key, xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"], cache_prepare=w.get("cache_prepare", False), rng_shard=w.get("rng_shard"))[1]
+        # the acting loop's shape: `rng, x0 = sample(rng, ...)` — the key is a device array, the next call's key is the rng this
+        # one returns (a PRNGKey built from a host integer per step would put a pageable H2D copy in front of every call)
+        if w.get("_key") is None:
+            from flowrl_hip import random as fr
+            w["_key"] = fr.PRNGKey(0, xT.device)
+        out = model.sample(w["_key"], xT, cond, False, "ddpm", particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), rng_impl=w["rng"], cache_prepare=w.get("cache_prepare", False), rng_shard=w.get("rng_shard"))
+        w["_key"] = out[0]
+        return out[1]
     return model.sample(None, xT, cond, False, "ddpm", noise=noise, particles=p, compute_dtype=cd, tile_policy=w.get("tile_policy", "auto"), cache_prepare=w.get("cache_prepare", False))[1]
 
 
@@ -403,6 +408,7 @@ def main():
                     help="draw the per-step noise in-kernel from a threefry key (FrlDesc.rng_impl) instead of reading a (T, B, A) tensor")
     ap.add_argument("--act", default="", help="ablation: override the activation")
     ap.add_argument("--layers", type=int, default=0, help="ablation: override the number of hidden layers")
+    ap.add_argument("--layer-norm", action="store_true", help="ablation: LayerNorm after every hidden Dense (MLP(layer_norm=True))")
     ap.add_argument("--kernel-only", action="store_true", help="ablation: print kernel ms only")
     ap.add_argument("--recompute", action="store_true", help="cfg5: plain forward with history + a backward that recomputes every step (round-1 path) instead of the training forward's stash")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU / gloo stand-in of the rank body (no GPU, not a measurement)")
@@ -470,6 +476,8 @@ def main():
         w["act"] = args.act
     if args.layers > 0:
         w["hidden"] = [w["hidden"][0]] * args.layers
+    if args.layer_norm:
+        w["ln"] = True
     B, T, A, S = w["B"], w["T"], w["A"], w["S"]
     model = build_model(w, dev)
     if args.kernel_only:
@@ -582,7 +590,7 @@ def main():
             flops_alg, k_ms = 3.0 * flops_alg, f_ms + b_ms
             vjp_parts = {"forward_ms": f_ms, "backward_ms": b_ms}
         achieved = flops_alg / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src = (None, None) if (vjp or args.act or args.layers or args.dtype != "f32" or args.rng != "none" or args.tile_policy != "auto") else pmc_traffic_bytes(args.workload, w)
+        traffic, traffic_src = (None, None) if (vjp or args.act or args.layers or args.layer_norm or args.dtype != "f32" or args.rng != "none" or args.tile_policy != "auto") else pmc_traffic_bytes(args.workload, w)
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "action samples/sec x T steps (chain-steps/s), fused sampler",

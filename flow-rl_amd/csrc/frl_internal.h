@@ -80,12 +80,12 @@ enum { W2_PICK_BY_BATCH = -1, W2_PICK_32 = 0, W2_PICK_16 = 1 };
 inline int plan_layout(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST, int force_tr = 0, size_t base = 0);
 
 // The 16x16x4 geometry at two waves per SIMD (csrc/sampler_rs.hip, frl_sampler_rs_kernel_w2) runs the plain sampler
-// only: f32 MLP backbone, 256 wide, no LayerNorm, no in-kernel draws, ddpm / ddim / Euler updates, condition rows in
+// only: f32 MLP backbone, 256 wide, no LayerNorm, ddpm / ddim / Euler updates (tensor-fed or keyed), condition rows in
 // the operand (x_dim <= 16, cond_dim <= 48) — plan_two_wave_shape, everything but the batch size — and a batch large
 // enough that every wave still gets two tiles.  A descriptor of that shape gets a workspace with BOTH geometries'
 // regions (Plan.w2_pair), so that a workspace prepared once serves frl_sampler_run at any batch size.
 inline bool plan_two_wave_shape(const FrlDesc& d, const Plan& p) {
-  if (d.dtype != FRL_DTYPE_F32 || d.backbone != FRL_BACKBONE_MLP || p.H != 256 || d.layer_norm != 0 || d.rng_impl != FRL_RNG_NONE) return false;
+  if (d.dtype != FRL_DTYPE_F32 || d.backbone != FRL_BACKBONE_MLP || p.H != 256 || d.layer_norm != 0) return false;     // in-kernel draws: the keyed variant of the build (EXT 6)
   if (d.kind != FRL_KIND_CNF && d.solver != FRL_SOLVER_DDPM && d.solver != FRL_SOLVER_DDIM) return false;
   if (d.tile_policy != FRL_TILE_AUTO && d.tile_policy != FRL_TILE_THROUGHPUT) return false;
   if (d.cond_embed) return false;

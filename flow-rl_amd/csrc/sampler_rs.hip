@@ -60,11 +60,13 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
 //      3 = 1 + critic scoring and best-of-N selection on the finished tile (CriticTab, frl_internal.h), 4 = 3 with a relu critic,
 //      5 = 1 + in-kernel threefry draws as micro-steps behind the MFMAs of the first hidden layer (no LayerNorm code: its
 //          presence alone costs the hot loops ~4 % in accumulator moves; LayerNorm + draws = EXT 2, draws up front)
-template <int TR, int H, int ACT, int NRX, int CKMAX, int EXT>
+//      6 = 0 + the same micro-step draws (the two-wave build's keyed variant: nothing of EXT 1, so that it fits 256 registers)
+template <int TR, int H, int ACT, int NRX, int CKMAX, int EXTV>
 __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab& ct) {
   typedef Geo<TR> G;
   typedef typename G::acc_t acc_t;
-  constexpr bool HAS_LN = (EXT == 2), HAS_RNG = (EXT == 5), HAS_CRITIC = (EXT == 3 || EXT == 4);
+  constexpr int EXT = (EXTV == 6) ? 0 : EXTV;
+  constexpr bool HAS_LN = (EXT == 2), HAS_RNG = (EXTV == 5 || EXTV == 6), HAS_CRITIC = (EXT == 3 || EXT == 4);
   constexpr int KS = G::KS, NR = G::NR, RING = G::RING;
   constexpr int NB = H / TR;        // output (and input) feature blocks per hidden layer
   constexpr int NG = NB / 4;        // 16-byte A-operand loads per k-step
@@ -578,14 +580,15 @@ frl_sampler_rs_fused_kernel(const KArgs a, const CriticTab ct) {
 }
 
 // Two waves per SIMD, 256 registers per lane: the 16-chain geometry of the plain sampler (EXT 0: 249 registers, no
-// spills; the EXT 1 / 2 paths do not fit).  Same body, same results per tile; the second wave fills the issue slots
+// spills; the EXT 1 / 2 paths do not fit) and its keyed variant (EXT 6: 256 registers, 47 dwords of spills, all but a dozen
+// reloads per step outside the MFMA loops — here the OTHER wave's MFMAs cover a wave's draws, which one wave per SIMD cannot).  Same body, same results per tile; the second wave fills the issue slots
 // the first leaves between its MFMAs and ring loads (+2 .. 2.6 % at cfg2, same-box A/B in DESIGN.md 5.2).  Picked by
 // plan_two_wave (frl_internal.h) for batches of >= 65536 chains.
-template <int ACT>
+template <int ACT, int RNG>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 frl_sampler_rs_kernel_w2(const KArgs a) {
   const CriticTab none{};
-  sampler_rs_body<16, 256, ACT, 4, 12, 0>(a, none);
+  sampler_rs_body<16, 256, ACT, 4, 12, RNG ? 6 : 0>(a, none);
 }
 
 // ---- launcher --------------------------------------------------------------------------------------
@@ -649,12 +652,14 @@ template <int ACT>
 static int launch_w2(const KArgs& a, hipStream_t stream) {
   if constexpr (ACT == FRL_ACT_IDENTITY) { set_error("two-wave build: no identity-activation unit"); return FRL_EINVAL; }
   else {
-    if (a.rng_impl != FRL_RNG_NONE || a.ws_ln != nullptr || a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.AR > 4 || a.CK > 12) {
+    if (a.ws_ln != nullptr || a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.AR > 4 || a.CK > 12) {
       set_error("two-wave build asked for a path it does not carry (plan / launch mismatch)"); return FRL_EINVAL; }
-    static thread_local size_t configured[16] = {0};
+    static thread_local size_t configured[2][16] = {{0}, {0}};
     char tag[64];
-    snprintf(tag, sizeof(tag), "frl_sampler_rs_kernel_w2<act %d>", ACT);
-    return launch_kern((const void*)frl_sampler_rs_kernel_w2<ACT>, tag, configured, 16, 256, 2 * MAX_WAVES, a, stream);
+    const int keyed = a.rng_impl != FRL_RNG_NONE;
+    snprintf(tag, sizeof(tag), "frl_sampler_rs_kernel_w2<act %d, draws %d>", ACT, keyed);
+    return launch_kern(keyed ? (const void*)frl_sampler_rs_kernel_w2<ACT, 1> : (const void*)frl_sampler_rs_kernel_w2<ACT, 0>, tag, configured[keyed], 16, 256,
+                       2 * MAX_WAVES, a, stream);
   }
 }
 

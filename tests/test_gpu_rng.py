@@ -142,6 +142,33 @@ def _t(a):
     return torch.from_numpy(a).cuda()
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_sampler_with_key_two_wave_build(impl):
+    """Large plain 256-wide batches take the 16-chain two-wave build; with a key its EXT 6 variant (micro-step draws, the
+    other wave's MFMAs beside them).  Same checks as above at 70 001 chains (a ragged last tile): the kernel fed
+    frl_random_normal's tensor for the oracle's iteration keys, and the float64 oracle on a slice."""
+    import torch
+    import flowrl_hip as fh
+    import flowrl_hip.random as fr
+    case = H.Case("ddpm-dql-two-wave", "ddpm", A=3, S=11, T=5, B=70001, seed=21)
+    params, xT, cond, noise, x0, xh, eh = _run_with_key(case, impl, seed=1234 + case.seed)
+    assert any("kernel_w2" in k and "draws 1" in k for k in fh.last_kernels()), fh.last_kernels()
+    keys, _ = tf.sampler_key_chain(case.kind, case.solver, case.T, tf.prng_key(1234 + case.seed), impl)
+    model = H.product_model(case, params)
+    dn = torch.stack([fr.normal(_t(keys[j]), xT.shape, impl) for j in range(case.T)])
+    _, y0, (yh, _) = model.sample(None, _t(xT), _t(cond), False, case.solver, noise=dn, history=True)
+    torch.cuda.synchronize()
+    assert any("kernel_w2" in k and "draws 0" in k for k in fh.last_kernels()), fh.last_kernels()
+    d0, dx = H.rel_err(x0, y0.cpu().numpy()), H.rel_err(xh, yh.cpu().numpy())
+    assert d0 <= 2e-6 and dx <= 2e-6, f"in-kernel draws vs frl_random_normal tensor: x0 {d0:.2e}, xt_hist {dx:.2e}"
+    sl = np.r_[0:2048, case.B - 2049:case.B]
+    sub = dataclasses.replace(case, B=len(sl))
+    ref0, refx, refe = H.oracle_run(sub, params, xT[sl], cond[sl], noise[:, sl], dtype=np.float64)
+    e0, ex, ee = H.rel_err(x0[sl], ref0), H.rel_err(xh[:, sl], refx), H.rel_err(eh[:, sl], refe)
+    print(f"two-wave keyed/{impl}: vs oracle x0 {e0:.2e} xt_hist {ex:.2e} eps_hist {ee:.2e}")
+    assert e0 <= 1e-4 and ex <= 1e-4 and ee <= 1e-4
+
+
 def test_explicit_noise_wins_and_rng_still_advances():
     import torch
     case = CASES[0]
