@@ -152,13 +152,13 @@ def test_sampler_with_key_two_wave_build(impl):
     import flowrl_hip.random as fr
     case = H.Case("ddpm-dql-two-wave", "ddpm", A=3, S=11, T=5, B=70001, seed=21)
     params, xT, cond, noise, x0, xh, eh = _run_with_key(case, impl, seed=1234 + case.seed)
-    assert any("kernel_w2" in k and "draws 1" in k for k in fh.last_kernels()), fh.last_kernels()
+    assert "kernel_w2<act 0, draws 1>" in fh.last_kernels(), fh.last_kernels()
     keys, _ = tf.sampler_key_chain(case.kind, case.solver, case.T, tf.prng_key(1234 + case.seed), impl)
     model = H.product_model(case, params)
     dn = torch.stack([fr.normal(_t(keys[j]), xT.shape, impl) for j in range(case.T)])
     _, y0, (yh, _) = model.sample(None, _t(xT), _t(cond), False, case.solver, noise=dn, history=True)
     torch.cuda.synchronize()
-    assert any("kernel_w2" in k and "draws 0" in k for k in fh.last_kernels()), fh.last_kernels()
+    assert "kernel_w2<act 0, draws 0>" in fh.last_kernels(), fh.last_kernels()
     d0, dx = H.rel_err(x0, y0.cpu().numpy()), H.rel_err(xh, yh.cpu().numpy())
     assert d0 <= 2e-6 and dx <= 2e-6, f"in-kernel draws vs frl_random_normal tensor: x0 {d0:.2e}, xt_hist {dx:.2e}"
     sl = np.r_[0:2048, case.B - 2049:case.B]
