@@ -40,4 +40,4 @@ for k in sorted(summ):
     print(f"{k}: mfma_busy/busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / max(g('SQ_BUSY_CYCLES'), 1):.3f} valu/mfma {g('SQ_INSTS_VALU') / max(g('SQ_INSTS_MFMA'), 1):.2f} "
           f"hbm_rd_MB {2 * g('FETCH_SIZE') / 1024:.1f} hbm_wr_MB {g('WRITE_SIZE') / 1024:.1f} lds_conflict/active {g('SQ_LDS_BANK_CONFLICT') / max(g('SQ_LDS_IDX_ACTIVE'), 1):.3f}")
 PY
-tail -1 $OUT/trace.log | cut -c1-400 > $OUT/summary/bench_line.json
+grep "^{\"metric\"" $OUT/trace.log | tail -1 > $OUT/summary/bench_line.json
