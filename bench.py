@@ -398,7 +398,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL all-gather of x0 (N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (H = 256 workloads)")
+                    help="f32 = bit-faithful kernel (the headline number); bf16 = stated-tolerance bf16-MFMA variant (256- and 512-wide MLP workloads)")
     ap.add_argument("--tile-policy", default="auto", choices=["auto", "throughput", "latency", "latency32", "latency16"],
                     help="f32 forward kernel build (FrlDesc.tile_policy); auto = latency build for small batches")
     ap.add_argument("--cache-prepare", action="store_true",

@@ -202,13 +202,16 @@ static int validate_desc(const FrlDesc* d) {
     return FRL_OK;
   }
   if (d->dtype == FRL_DTYPE_BF16) {
-    // bf16 MFMA variant (csrc/sampler_bf16.hip): 256-wide predictor, bf16 operands / f32 accumulate / f32 chain state
+    // bf16 MFMA variant (csrc/sampler_bf16.hip): 256- or 512-wide predictor, bf16 operands / f32 accumulate / f32 chain state
+    const int hw = d->hidden[0];
+    if (hw != 256 && hw != 512) { set_error("bf16 variant: hidden width 256 or 512 required (hidden[0] = %d)", hw); return FRL_EUNSUPPORTED; }
     for (int l = 0; l < d->n_hidden; ++l)
-      if (d->hidden[l] != 256) { set_error("bf16 variant: hidden widths must all be 256 (hidden[%d] = %d)", l, d->hidden[l]); return FRL_EUNSUPPORTED; }
-    if (d->x_dim > 32 || d->cond_dim > 128) { set_error("bf16 variant: x_dim <= 32 and cond_dim <= 128 required (got %d, %d)", d->x_dim, d->cond_dim); return FRL_EUNSUPPORTED; }
+      if (d->hidden[l] != hw) { set_error("bf16 variant: hidden widths must all be equal (hidden[%d] = %d, hidden[0] = %d)", l, d->hidden[l], hw); return FRL_EUNSUPPORTED; }
+    if (hw == 256 && (d->x_dim > 32 || d->cond_dim > 128)) { set_error("bf16 variant: x_dim <= 32 and cond_dim <= 128 required (got %d, %d)", d->x_dim, d->cond_dim); return FRL_EUNSUPPORTED; }
+    if (hw == 512 && (d->x_dim > 16 || d->cond_dim > 64)) { set_error("bf16 variant, 512 wide: x_dim <= 16 and cond_dim <= 64 required (got %d, %d)", d->x_dim, d->cond_dim); return FRL_EUNSUPPORTED; }
     if (d->act != FRL_ACT_MISH && d->act != FRL_ACT_SILU && d->act != FRL_ACT_RELU && d->act != FRL_ACT_GELU_TANH) {
       set_error("bf16 variant: activation %d not compiled in (mish / silu / relu / gelu_tanh)", d->act); return FRL_EUNSUPPORTED; }
-    if (bf16_lds_bytes(d->steps, d->n_hidden) > 160 * 1024) { set_error("bf16 variant: steps = %d does not fit the LDS tables", d->steps); return FRL_EUNSUPPORTED; }
+    if (bf16_lds_bytes(d->steps, d->n_hidden, hw) > 160 * 1024) { set_error("bf16 variant: steps = %d does not fit the LDS tables", d->steps); return FRL_EUNSUPPORTED; }
     return FRL_OK;
   }
   for (int l = 0; l < d->n_hidden; ++l)
@@ -515,6 +518,7 @@ static int validate_bwd(const FrlDesc* d) {
   if (d->backbone != FRL_BACKBONE_MLP) { set_error("VJP: residual backbones have no backward kernel"); return FRL_EUNSUPPORTED; }
   if (d->dtype == FRL_DTYPE_BF16) {
     // bf16-MFMA VJP (csrc/sampler_bwd_bf16.hip): the narrow instantiation of the bf16 forward kernel
+    if (pl.H != 256) { set_error("bf16 VJP: only the 256-wide build has a backward kernel"); return FRL_EUNSUPPORTED; }
     if (pl.A > 16 || pl.C > 32 || pl.A + pl.C > 32) { set_error("bf16 VJP: x_dim <= 16 and x_dim + cond_dim <= 32 required (got %d, %d)", pl.A, pl.C); return FRL_EUNSUPPORTED; }
     if (d->cond_embed) { set_error("bf16 VJP: cond_embedding backward not built"); return FRL_EUNSUPPORTED; }
     if (d->act != FRL_ACT_MISH && d->act != FRL_ACT_SILU && d->act != FRL_ACT_RELU) { set_error("bf16 VJP: activation %d has no backward kernel (mish / silu / relu)", d->act); return FRL_EUNSUPPORTED; }

@@ -62,8 +62,8 @@ struct Plan {
   int bf16;             // 1: desc.dtype == FRL_DTYPE_BF16
   int bf_nxk;           // layer-0 x k-steps (16 action rows each): 1 (A <= 16 and C <= 32) or 2
   int bf_cks;           // layer-0 cond k-steps the instantiation runs (2 or 8; k-steps beyond ceil(C / 16) are zero)
-  int bf_l0c;           // layer-0 chunks = ceil(8 (nxk + cks) / 32)
-  int bf_ns;            // chunks per step = l0c + 4 (L - 1) + 1
+  int bf_l0c;           // layer-0 chunks = ceil((H / 32) (nxk + cks) / 32)
+  int bf_ns;            // chunks per step = l0c + (H / 32)(H / 16) / 32 (L - 1) + 1   (4 per hidden layer at 256, 16 at 512)
   size_t off_bf16;      // float offset of the image (bf_ns * 8192 floats)
   int w2_pair;          // 1: the workspace holds BOTH geometries' tables and packed images (32-chain region, then the
                         //    16-chain region), so that it does not depend on the batch size; this Plan is one of the two
@@ -156,8 +156,10 @@ inline int plan_layout(const FrlDesc& d, Plan& p, int flags, int force_tr, size_
   p.bf16 = (d.dtype == FRL_DTYPE_BF16) ? 1 : 0;
   p.bf_nxk = (p.A <= 16 && p.C <= 32) ? 1 : 2;   // narrow instantiation <8, 2> or wide <16, 8>
   p.bf_cks = (p.bf_nxk == 1) ? 2 : 8;
-  p.bf_l0c = (8 * (p.bf_nxk + p.bf_cks) + 31) / 32;
-  p.bf_ns = p.bf_l0c + 4 * (p.L - 1) + 1;
+  if (p.H == 512) { p.bf_nxk = 1; p.bf_cks = 4; } // the 512-wide build: one instantiation <8, 4> (x_dim <= 16, cond_dim <= 64)
+  const int bf_nob = p.H / 32;                    // output blocks per layer; a hidden layer is nob * (H / 16) pieces of 1 KB
+  p.bf_l0c = (bf_nob * (p.bf_nxk + p.bf_cks) + 31) / 32;
+  p.bf_ns = p.bf_l0c + (bf_nob * (p.H / 16) / 32) * (p.L - 1) + 1;
   p.off_bf16 = take(p.bf16 ? (size_t)p.bf_ns * (BF_CHUNK_BYTES / 4) : 0);
   // Everything above is written by frl_sampler_prepare and sits at offsets that do not depend on n_states; the per-state
   // rows below are written by frl_sampler_run itself.  So a workspace prepared once serves runs at any batch size it is
@@ -493,8 +495,8 @@ inline bool sampler_lat16_supports(const KArgs& a) {
   return a.H == 256 && a.A <= 16 && (a.C + 3) / 4 <= 32 && lat_lds_bytes(a.NE, a.L, a.H, false, a.ws_ln != nullptr) <= 160 * 1024;
 }
 int launch_prepare_bf16(const FrlParams& p, const Plan& pl, float* ws, hipStream_t stream);   // bf16 weight stream image
-int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256)
-size_t bf16_lds_bytes(int T, int L);
+int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256 or 512)
+size_t bf16_lds_bytes(int T, int L, int H = 256);
 int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim, const float* w0, const float* b0,
                        const float* w1, const float* b1, float* cfeat, hipStream_t stream);
 int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, const float* w, const float* b, float* zs,

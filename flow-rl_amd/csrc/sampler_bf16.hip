@@ -1,4 +1,5 @@
-// bf16-MFMA variant of the fused T-step sampler (FrlDesc.dtype = FRL_DTYPE_BF16; hidden width 256).
+// bf16-MFMA variant of the fused T-step sampler (FrlDesc.dtype = FRL_DTYPE_BF16; hidden width 256, or 512 — see the end
+// of this comment).
 // BASELINE north star: "fp32 for bit-faithful runs, bf16 as a stated-tolerance variant".  Same reference semantics
 // as sampler_rs.hip (DDPM.sample ddpm.py:184-221, ContinuousDDPM.sample continuous_ddpm.py:149-222, CNF.sample
 // cnf.py:122-141; network ddpm.py:83-95 + mlp.py:25-33); what changes is the arithmetic of the Dense layers:
@@ -25,6 +26,11 @@
 // 32 KB chunks (2 output blocks) by LDS-DMA into a 4-slot ring, three chunks in flight, one s_barrier per chunk,
 // read back with one ds_read_b128 per MFMA.  Plain f32 VALU only: v_pk_*_f32 beside bf16 MFMAs is an anti-lever
 // (measured +8.5 cycles each) — this TU is built with -fno-slp-vectorize so the compiler does not pack either.
+//
+// 512 wide (cfg3's FQL net; SURVEY 7 "hard parts": bf16 weights are what lets the 3 x 512 x 512 stream sit in an XCD's L2):
+// the same body with 16 output blocks of 32 k-steps.  The packed inputs and outputs of a layer are then 2 x 128 registers,
+// so this build runs ONE wave per SIMD (512 registers) on 128-chain workgroup tiles: four waves share the stream, each
+// DMAs 8 of a chunk's 32 pieces.  A hidden layer is 16 chunks (one output block each), Dense_L fills one chunk.
 #include "frl_bf16.h"
 #include "frl_rng.h"
 
@@ -35,10 +41,11 @@ struct PBfArgs {
   const float* kernel[FRL_MAX_HIDDEN + 1];
   unsigned short* img;
   int A, C, Dp, L, nxk, k0, l0c, ns;   // k0 = layer-0 k-steps per output block (x k-steps + compiled cond k-steps)
+  int H;
 };
 
 __global__ void __launch_bounds__(256) frl_prepare_bf16_kernel(const PBfArgs p) {
-  constexpr int H = 256;
+  const int H = p.H, NOB = H >> 5, NKH = H >> 4, HC = (NOB * NKH) >> 5;   // output blocks, hidden k-steps, chunks per hidden layer
   const long long total = (long long)p.ns * (BF_CHUNK_BYTES / 2);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(idx / (BF_CHUNK_BYTES / 2));
@@ -49,7 +56,7 @@ __global__ void __launch_bounds__(256) frl_prepare_bf16_kernel(const PBfArgs p) 
     if (c < p.l0c) {                                   // Dense_0: per output block, x k-steps then cond k-steps
       const int pi = c * 32 + piece;                   //   (time rows are in tb; k-steps beyond the data are zero)
       const int ob = pi / p.k0, ks = pi - ob * p.k0;
-      if (ob < 8) {
+      if (ob < NOB) {
         if (ks < p.nxk) {
           const int row = BF_ROWR(8 * ks + e) + 4 * s;
           if (row < p.A) v = p.kernel[0][(size_t)row * H + 32 * ob + i];
@@ -58,12 +65,13 @@ __global__ void __launch_bounds__(256) frl_prepare_bf16_kernel(const PBfArgs p) 
           if (ci < p.C) v = p.kernel[0][(size_t)(p.A + p.Dp + ci) * H + 32 * ob + i];
         }
       }
-    } else if (c < p.l0c + 4 * (p.L - 1)) {            // hidden Dense_l: chunk = output blocks 2 hc, 2 hc + 1
-      const int hc = c - p.l0c, l = 1 + (hc >> 2);
-      const int ob = 2 * (hc & 3) + (piece >> 4), ks = piece & 15;
+    } else if (c < p.l0c + HC * (p.L - 1)) {           // hidden Dense_l: NOB x NKH pieces, output-block-major (at 256: chunk =
+      const int hc = c - p.l0c, l = 1 + hc / HC;       //   output blocks 2 hc, 2 hc + 1; at 512: one block per chunk)
+      const int pl = (hc - (l - 1) * HC) * 32 + piece;
+      const int ob = pl / NKH, ks = pl - ob * NKH;
       const int feat = 32 * (ks >> 1) + BF_ROWR(8 * (ks & 1) + e) + 4 * s;
       v = p.kernel[l][(size_t)feat * H + 32 * ob + i];
-    } else if (piece < 16) {                           // Dense_L, one output block (rows >= A are zero)
+    } else if (piece < NKH) {                          // Dense_L, one output block (rows >= A are zero)
       const int ks = piece;
       const int feat = 32 * (ks >> 1) + BF_ROWR(8 * (ks & 1) + e) + 4 * s;
       if (i < p.A) v = p.kernel[p.L][(size_t)feat * p.A + i];
@@ -77,8 +85,8 @@ int launch_prepare_bf16(const FrlParams& prm, const Plan& pl, float* ws, hipStre
   for (int l = 0; l <= pl.L; ++l) p.kernel[l] = prm.kernel[l];
   p.img = (unsigned short*)(ws + pl.off_bf16);
   p.A = pl.A; p.C = pl.C; p.Dp = pl.Dp; p.L = pl.L;
-  p.nxk = pl.bf_nxk; p.k0 = pl.bf_nxk + pl.bf_cks; p.l0c = pl.bf_l0c; p.ns = pl.bf_ns;
-  hipLaunchKernelGGL(frl_prepare_bf16_kernel, dim3(64), dim3(256), 0, stream, p);
+  p.nxk = pl.bf_nxk; p.k0 = pl.bf_nxk + pl.bf_cks; p.l0c = pl.bf_l0c; p.ns = pl.bf_ns; p.H = pl.H;
+  hipLaunchKernelGGL(frl_prepare_bf16_kernel, dim3(pl.H == 256 ? 64 : 256), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("bf16 prepare launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
@@ -127,20 +135,20 @@ __device__ __forceinline__ u32x4 pack_act(const f32x16& p) {
 // One Dense layer, output-block-major: for each of the NOB output blocks, NK MFMAs into one accumulator; the
 // activation + packing of the previous block (-> bout[2 ob], bout[2 ob + 1]) is issued alongside.  Pieces are read
 // through a 4-deep register ring; a chunk boundary (barrier + next DMA) every 32 pieces.
-template <int ACT, int NK, typename BFun, typename NextChunk>
-__device__ __forceinline__ void layer_bf(u32x4 (&bout)[16], BFun&& bfun, const float* sb, NextChunk& next_chunk,
+template <int ACT, int NK, int NOB, typename BFun, typename NextChunk>
+__device__ __forceinline__ void layer_bf(u32x4 (&bout)[2 * NOB], BFun&& bfun, const float* sb, NextChunk& next_chunk,
                                          unsigned lane16, int ls) {
-  constexpr int NP = 8 * NK, R = 4;
+  constexpr int NP = NOB * NK, R = 4;
   f32x16 acc[2];
   u32x4 ring[R];
   const char* sl = next_chunk() + lane16;
   const char* sl_next = sl;
   sfor<R>([&](auto PI) { constexpr int p = decltype(PI)::value; ring[p] = *(const u32x4*)(sl + p * 1024); });
-  sfor<8>([&](auto OI) {
+  sfor<NOB>([&](auto OI) {
     constexpr int ob = decltype(OI)::value;
     sfor<4>([&](auto VI) {                               // accumulator init = bias (permuted table: 4 x 16 B per block)
       constexpr int v = decltype(VI)::value;
-      const f32x4 bv = *(const f32x4*)(sb + (ls * 8 + ob) * 16 + 4 * v);
+      const f32x4 bv = *(const f32x4*)(sb + (ls * NOB + ob) * 16 + 4 * v);
       sfor<4>([&](auto JI) { constexpr int j = decltype(JI)::value; acc[ob & 1][4 * v + j] = bv[j]; });
     });
     if constexpr (ob > 0) {
@@ -166,14 +174,15 @@ __device__ __forceinline__ void layer_bf(u32x4 (&bout)[16], BFun&& bfun, const f
     }
     __builtin_amdgcn_sched_barrier(0);
   });
-  bout[14] = pack_act<ACT, 0>(acc[1]);
-  bout[15] = pack_act<ACT, 8>(acc[1]);
+  bout[2 * NOB - 2] = pack_act<ACT, 0>(acc[(NOB - 1) & 1]);
+  bout[2 * NOB - 1] = pack_act<ACT, 8>(acc[(NOB - 1) & 1]);
 }
 
-template <int ACT, int NRX, int CKS>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-frl_sampler_bf16_kernel(const KArgs a) {
-  constexpr int H = 256, NXK = NRX / 8, K0 = NXK + CKS, NT = 512;
+template <int H, int NW, int ACT, int NRX, int CKS>
+__device__ __forceinline__ void sampler_bf16_body(const KArgs& a) {
+  constexpr int NXK = NRX / 8, K0 = NXK + CKS, NT = 64 * NW;
+  constexpr int NOB = H / 32, NKH = H / 16;     // output blocks per layer, k-steps of a hidden layer
+  constexpr int PPW = 32 / NW;                  // pieces of a chunk each wave DMAs (4 or 8)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -182,11 +191,11 @@ frl_sampler_bf16_kernel(const KArgs a) {
 
   // bias tables, permuted so that a lane half reads the 16 accumulator inits of a block as 4 x 16 B:
   // tbl[(s * 8 + ob) * 16 + r] = bias[32 ob + ROWR(r) + 4 s]
-  float* s_tb = (float*)(smem + BF_NBUF * BF_CHUNK_BYTES);   // [T][256]
-  float* s_bh = s_tb + a.T * H;                               // [L-1][256]
+  float* s_tb = (float*)(smem + BF_NBUF * BF_CHUNK_BYTES);   // [T][H]
+  float* s_bh = s_tb + a.T * H;                               // [L-1][H]
   float* s_bl = s_bh + (a.L - 1) * H;                         // [32] padded last-layer bias (natural order)
   float* s_coef = s_bl + LAST_PAD;                            // [T][8]
-  auto perm_src = [](int p) { const int s = p >> 7, ob = (p >> 4) & 7, r = p & 15; return 32 * ob + BF_ROWR(r) + 4 * s; };
+  auto perm_src = [](int p) { const int s = p / (16 * NOB), ob = (p >> 4) & (NOB - 1), r = p & 15; return 32 * ob + BF_ROWR(r) + 4 * s; };
   for (int idx = tid; idx < a.T * H; idx += NT) s_tb[idx] = a.ws_tb[(idx & ~(H - 1)) + perm_src(idx & (H - 1))];
   for (int l = 1; l < a.L; ++l) {
     const float* bp = pick_ptr_rs(a.bh, l - 1);
@@ -198,11 +207,14 @@ frl_sampler_bf16_kernel(const KArgs a) {
 
   // ---- weight stream: the same bf_ns chunks every step of every tile, three in flight ----------------------
   const int NS = a.bf_ns;
-  const char* img = (const char*)a.ws_bf16 + wave * 4096 + lane * 16;   // this wave DMAs pieces 4w .. 4w+3 of a chunk
+  const char* img = (const char*)a.ws_bf16 + wave * (PPW * 1024) + lane * 16;   // this wave DMAs pieces PPW w .. PPW w + PPW - 1 of a chunk
   auto issue = [&](int seq, unsigned boff) {
     const char* src = img + (size_t)seq * BF_CHUNK_BYTES;
-    char* dst = smem + boff + wave * 4096;
-    sfor<4>([&](auto II) { constexpr int i = decltype(II)::value; dma16_bf<i * 1024>(src, dst); });
+    char* dst = smem + boff + wave * (PPW * 1024);
+    sfor<PPW / 4>([&](auto GI) {     // the instruction's immediate offset reaches 4 pieces; groups of 4 move both bases
+      constexpr int g = decltype(GI)::value;
+      sfor<4>([&](auto II) { constexpr int i = decltype(II)::value; dma16_bf<i * 1024>(src + g * 4096, dst + g * 4096); });
+    });
   };
   auto wrap_seq = [&](int s) { return s >= NS ? s - NS : s; };
   issue(0, 0);
@@ -214,7 +226,8 @@ frl_sampler_bf16_kernel(const KArgs a) {
   // wave is past the previous chunk (barrier), so that chunk's slot can take the chunk three ahead.
   auto next_chunk = [&]() -> const char* {
 #if !defined(FRL_BF_EXP_NOBAR)   // (timing experiments only: results are wrong without the wait / barrier / DMA)
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
 #if !defined(FRL_BF_EXP_NODMA)
@@ -228,8 +241,8 @@ frl_sampler_bf16_kernel(const KArgs a) {
   };
 
   const unsigned lane16 = lane * 16;
-  const int ntiles = (int)((a.B + 255) / 256);
-  u32x4 bin[16], bout[16];    // packed bf16 layer inputs / outputs: k-step ks <-> features of block ks >> 1, half ks & 1
+  const int ntiles = (int)((a.B + NW * 32 - 1) / (NW * 32));
+  u32x4 bin[NKH], bout[NKH];    // packed bf16 layer inputs / outputs: k-step ks <-> features of block ks >> 1, half ks & 1
 
 #ifdef FRL_BF_EXP_TIMING
   long long tsec[6] = {0, 0, 0, 0, 0, 0}; long long tmark = __builtin_amdgcn_s_memtime();
@@ -238,7 +251,7 @@ frl_sampler_bf16_kernel(const KArgs a) {
 #define FRL_TMARK(k)
 #endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long chain = (long long)tile * 256 + wave * 32 + li;
+    const long long chain = (long long)tile * (NW * 32) + wave * 32 + li;
     const bool valid = chain < a.B;
     const long long state = (a.particles == 1) ? chain : chain / a.particles;
 
@@ -274,15 +287,15 @@ frl_sampler_bf16_kernel(const KArgs a) {
           constexpr int ks = decltype(KI)::value;
           if constexpr (ks < NXK) return bx[ks]; else return cbp[ks - NXK];
         };
-        layer_bf<ACT, K0>(bin, b0, s_tb + j * H, next_chunk, lane16, ls);
+        layer_bf<ACT, K0, NOB>(bin, b0, s_tb + j * H, next_chunk, lane16, ls);
       }
       FRL_TMARK(2)
 
       // ---------------- hidden Dense_l : h_l = act(b_l + W_l^T h_{l-1}) -------------------------------
       for (int l = 1; l < a.L; ++l) {
         auto bh = [&](auto KI) -> u32x4 { return bin[decltype(KI)::value]; };
-        layer_bf<ACT, 16>(bout, bh, s_bh + (l - 1) * H, next_chunk, lane16, ls);
-        sfor<16>([&](auto KI) { constexpr int k = decltype(KI)::value; bin[k] = bout[k]; });
+        layer_bf<ACT, NKH, NOB>(bout, bh, s_bh + (l - 1) * H, next_chunk, lane16, ls);
+        sfor<NKH>([&](auto KI) { constexpr int k = decltype(KI)::value; bin[k] = bout[k]; });
       }
       FRL_TMARK(3)
 
@@ -307,10 +320,10 @@ frl_sampler_bf16_kernel(const KArgs a) {
         });
         u32x4 awl[4];
         sfor<4>([&](auto KI) { constexpr int ks = decltype(KI)::value; awl[ks] = *(const u32x4*)(sl + ks * 1024); });
-        sfor<16>([&](auto KI) {
+        sfor<NKH>([&](auto KI) {
           constexpr int ks = decltype(KI)::value;
           O = mfma_bf(awl[ks & 3], bin[ks], O);
-          if constexpr (ks + 4 < 16) awl[ks & 3] = *(const u32x4*)(sl + (ks + 4) * 1024);
+          if constexpr (ks + 4 < NKH) awl[ks & 3] = *(const u32x4*)(sl + (ks + 4) * 1024);
         });
       }
       FRL_TMARK(4)
@@ -376,6 +389,20 @@ frl_sampler_bf16_kernel(const KArgs a) {
   __builtin_amdgcn_s_barrier();
 }
 
+// 256 wide: eight waves per workgroup, two per SIMD (256 registers each), 256-chain workgroup tiles
+template <int ACT, int NRX, int CKS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+frl_sampler_bf16_kernel(const KArgs a) {
+  sampler_bf16_body<256, 8, ACT, NRX, CKS>(a);
+}
+
+// 512 wide: four waves per workgroup, one per SIMD (512 registers), 128-chain workgroup tiles; x_dim <= 16, cond_dim <= 64
+template <int ACT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+frl_sampler_bf16_h512_kernel(const KArgs a) {
+  sampler_bf16_body<512, 4, ACT, 8, 4>(a);
+}
+
 // ---- launcher ------------------------------------------------------------------------------------------------
 template <int ACT, int NRX, int CKS>
 static int launch_inst_bf(const KArgs& a, int grid, size_t lds, hipStream_t stream) {
@@ -390,15 +417,29 @@ static int launch_inst_bf(const KArgs& a, int grid, size_t lds, hipStream_t stre
 }
 
 template <int ACT>
+static int launch_h512_bf(const KArgs& a, int grid, size_t lds, hipStream_t stream) {
+  if (a.bf_nxk != 1 || a.bf_cks != 4) { set_error("bf16 512-wide kernel: x_dim %d / cond_dim %d outside its operand budget (x_dim <= 16, cond_dim <= 64)", a.A, a.C); return FRL_EUNSUPPORTED; }
+  auto kern = frl_sampler_bf16_h512_kernel<ACT>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e)); return FRL_EHIP; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("bf16 sampler launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
+  note_kernel("frl_sampler_bf16_h512_kernel<act %d> [grid %d]", ACT, grid);
+  return FRL_OK;
+}
+
+template <int ACT>
 static int launch_act_bf(const KArgs& a, int grid, size_t lds, hipStream_t stream) {
+  if (a.H == 512) return launch_h512_bf<ACT>(a, grid, lds, stream);
   if (a.bf_nxk == 1 && a.bf_cks == 2) return launch_inst_bf<ACT, 8, 2>(a, grid, lds, stream);
   if (a.bf_nxk == 2 && a.bf_cks == 8) return launch_inst_bf<ACT, 16, 8>(a, grid, lds, stream);
   set_error("bf16 kernel: x_dim %d / cond_dim %d outside the compiled operand budgets (x_dim <= 32, cond_dim <= 128)", a.A, a.C);
   return FRL_EUNSUPPORTED;
 }
 
-size_t bf16_lds_bytes(int T, int L) {
-  return (size_t)BF_NBUF * BF_CHUNK_BYTES + sizeof(float) * ((size_t)T * 256 + (size_t)(L - 1) * 256 + LAST_PAD + (size_t)T * COEF_STRIDE);
+size_t bf16_lds_bytes(int T, int L, int H) {
+  return (size_t)BF_NBUF * BF_CHUNK_BYTES + sizeof(float) * ((size_t)T * H + (size_t)(L - 1) * H + LAST_PAD + (size_t)T * COEF_STRIDE);
 }
 
 int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream) {
@@ -406,9 +447,11 @@ int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-  const long long ntiles = (a.B + 255) / 256;
+  if (a.H != 256 && a.H != 512) { set_error("bf16 kernel: hidden width %d has no build (256 / 512)", a.H); return FRL_EUNSUPPORTED; }
+  const int tile = (a.H == 256) ? 256 : 128;     // chains per workgroup
+  const long long ntiles = (a.B + tile - 1) / tile;
   const int grid = (int)(ntiles < ncu ? ntiles : ncu);
-  const size_t lds = bf16_lds_bytes(a.T, a.L);
+  const size_t lds = bf16_lds_bytes(a.T, a.L, a.H);
   if (lds > 160 * 1024) { set_error("bf16 kernel: steps=%d needs %zu B of LDS (> 160 KiB)", a.T, lds); return FRL_EUNSUPPORTED; }
   switch (d.act) {
 #if !defined(FRL_BF_ONLY_MISH)

@@ -60,6 +60,10 @@ CASES = [
            schedule="cosine", seed=6, bf16=True),
     H.Case("cfg4_cond_embed", "cddpm", A=17, S=376, T=20, B=8 * 64, particles=64, temb="learnable_fourier",
            schedule="cosine", cond_embed=True, seed=7, bf16=True),
+    # the 512-wide build (one wave per SIMD, 128-chain workgroup tiles): cfg3's FQL net, ragged batches, a DDPM net with a time branch
+    H.Case("cfg3_fql_h512", "cnf", A=8, S=39, T=10, B=700, hidden=(512,) * 4, act="gelu_tanh", temb=None, clip=False, seed=8, bf16=True),
+    H.Case("h512_ddpm_mish", "ddpm", A=6, S=17, T=5, B=130, hidden=(512, 512), seed=9, bf16=True),
+    H.Case("h512_one_hidden_relu", "ddpm", A=16, S=64, T=4, B=64, hidden=(512,), act="relu", schedule="linear", seed=10, bf16=True),
 ]
 
 
@@ -70,8 +74,9 @@ def test_bf16_variant(case):
 
 def test_bf16_unsupported_is_loud():
     import flowrl_hip as fh
-    case = H.Case("h512", "cnf", A=8, S=39, T=10, B=64, hidden=(512,) * 4, act="gelu_tanh", temb=None, clip=False, bf16=True)
-    params, xT, cond, noise = H.make_inputs(case)
-    model = H.product_model(case, params)
-    with pytest.raises(fh.FlowRLHipUnsupported):
-        H.product_run(case, model, xT, cond, noise)
+    for case in (H.Case("h128", "cnf", A=8, S=39, T=10, B=64, hidden=(128,) * 2, act="gelu_tanh", temb=None, clip=False, bf16=True),
+                 H.Case("h512_wide_cond", "cnf", A=8, S=100, T=10, B=64, hidden=(512,) * 2, act="gelu_tanh", temb=None, clip=False, bf16=True)):
+        params, xT, cond, noise = H.make_inputs(case)
+        model = H.product_model(case, params)
+        with pytest.raises(fh.FlowRLHipUnsupported):
+            H.product_run(case, model, xT, cond, noise)
