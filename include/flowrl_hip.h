@@ -81,7 +81,8 @@ extern "C" {
 #define FRL_LN_POST_ACT 2 /* flowrl/agent/offline/fql/network.py:26-30 */
 
 #define FRL_DTYPE_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the bit-faithful path */
-#define FRL_DTYPE_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16) operands, f32 accumulate / activations / chain state: stated tolerance */
+#define FRL_DTYPE_BF16 1 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16) operands, f32 accumulate / activations / chain state: stated tolerance;
+                          * forward: hidden width 256 (x_dim <= 32, cond_dim <= 128) or 512 (x_dim <= 16, cond_dim <= 64) */
 
 /* Static description of one sampler call — the analogue of the reference's jit static_argnames
  * plus the pytree_node=False fields of DDPM / ContinuousDDPM / ContinuousNormalizingFlow
