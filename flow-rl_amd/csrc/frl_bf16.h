@@ -34,4 +34,35 @@ __device__ __forceinline__ void dma16_bf(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
 }
 
+// One solver update on a chain-state element, f32: shared by the bf16 sampler and the bf16 training forward, which must agree
+// bit for bit (tests/test_gpu_vjp_bf16.py).  Contraction is OFF: which of two products the compiler fuses into an fma is
+// otherwise its choice per call site, and the two kernels did get different choices once their bodies diverged.
+__device__ __forceinline__ float bf_solver_update(int mode, int clip, float x_min, float x_max, float c0, float c1, float c2,
+                                                  float c3, float c4, float c5, float xt, float eps, float z) {
+#pragma clang fp contract(off)
+  float xn;
+  if (mode == MODE_DDPM_DDPM) {
+    float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
+    if (clip) x0h = fminf(fmaxf(x0h, x_min), x_max);        // ddpm.py:200-201
+    xn = c2 * (c3 * x0h + c4 * xt);                         // ddpm.py:202-203
+    xn += c5 * z;                                           // ddpm.py:206
+  } else if (mode == MODE_DDPM_DDIM) {
+    xn = c0 * (xt - c1 * eps) + c2 * eps;                   // ddpm.py:211
+    if (clip) xn = fminf(fmaxf(xn, x_min), x_max);
+  } else if (mode == MODE_CDDPM_DDPM) {
+    float x0h = (xt - c1 * eps) / c0;                       // continuous_ddpm.py:165
+    if (clip) x0h = fminf(fmaxf(x0h, x_min), x_max);
+    xn = c2 * x0h + c3 * xt;                                // :173
+    xn += c5 * z;                                           // :174
+  } else if (mode == MODE_CDDPM_DDIM) {
+    float x0h = (xt - c1 * eps) / c0;
+    if (clip) x0h = fminf(fmaxf(x0h, x_min), x_max);
+    xn = c2 * x0h + c3 * eps;                               // :177
+  } else {
+    xn = xt + eps / c0;                                     // cnf.py:108
+    if (clip) xn = fminf(fmaxf(xn, x_min), x_max);
+  }
+  return xn;
+}
+
 }  // namespace frl

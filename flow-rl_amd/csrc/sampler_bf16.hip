@@ -34,6 +34,13 @@
 #include "frl_bf16.h"
 #include "frl_rng.h"
 
+#ifndef FRL_BF_RING_H512
+#define FRL_BF_RING_H512 8   // A/B at cfg3 (gelu-tanh): 4 -> 20.96 ms, 8 -> 19.4 .. 19.9, 12 / 16 no further gain
+#endif
+#ifndef FRL_BF_TICK
+#define FRL_BF_TICK 3          // one refill DMA per three MFMAs (2 and 1: no better)
+#endif
+
 namespace frl {
 
 // ---- weight stream image ------------------------------------------------------------------------------------
@@ -135,10 +142,10 @@ __device__ __forceinline__ u32x4 pack_act(const f32x16& p) {
 // One Dense layer, output-block-major: for each of the NOB output blocks, NK MFMAs into one accumulator; the
 // activation + packing of the previous block (-> bout[2 ob], bout[2 ob + 1]) is issued alongside.  Pieces are read
 // through a 4-deep register ring; a chunk boundary (barrier + next DMA) every 32 pieces.
-template <int ACT, int NK, int NOB, typename BFun, typename NextChunk>
-__device__ __forceinline__ void layer_bf(u32x4 (&bout)[2 * NOB], BFun&& bfun, const float* sb, NextChunk& next_chunk,
+template <int ACT, int NK, int NOB, typename BFun, typename NextChunk, typename Tick>
+__device__ __forceinline__ void layer_bf(u32x4 (&bout)[2 * NOB], BFun&& bfun, const float* sb, NextChunk& next_chunk, Tick& dma_tick,
                                          unsigned lane16, int ls) {
-  constexpr int NP = NOB * NK, R = 4;
+  constexpr int NP = NOB * NK, R = (NOB == 16) ? FRL_BF_RING_H512 : 4;    // pieces the register ring runs ahead of the MFMAs
   f32x16 acc[2];
   u32x4 ring[R];
   const char* sl = next_chunk() + lane16;
@@ -159,6 +166,7 @@ __device__ __forceinline__ void layer_bf(u32x4 (&bout)[2 * NOB], BFun&& bfun, co
       constexpr int ks = decltype(KI)::value;
       constexpr int p = ob * NK + ks;
       acc[ob & 1] = mfma_bf(ring[p % R], bfun(KI), acc[ob & 1]);
+      if constexpr (p % FRL_BF_TICK == 0) dma_tick();    // (512-wide build) one refill piece per FRL_BF_TICK MFMAs
       if constexpr (p + R < NP) {
         constexpr int q = p + R;
         if constexpr ((q & 31) == 0) sl_next = next_chunk() + lane16;   // the ring runs R pieces ahead of the MFMAs
@@ -216,6 +224,21 @@ __device__ __forceinline__ void sampler_bf16_body(const KArgs& a) {
       sfor<4>([&](auto II) { constexpr int i = decltype(II)::value; dma16_bf<i * 1024>(src + g * 4096, dst + g * 4096); });
     });
   };
+  // One wave per SIMD (the 512-wide build) feels every DMA instruction: eight in a row behind the chunk barrier cost 3.5 of
+  // 21 ms at cfg3 (measured with the DMA compiled out).  There the refill of the freed slot is SPREAD: next_chunk only
+  // records it, dma_tick() issues one piece per three MFMAs, and the next chunk boundary flushes what is left.
+  constexpr bool SPREAD = (NW == 4);
+  const char* dma_src = img;
+  char* dma_dst = smem;
+  int dma_left = 0;
+  auto dma_tick = [&]() {
+    if constexpr (SPREAD) {
+      if (dma_left > 0) {
+        dma16_bf<0>(dma_src, dma_dst);
+        dma_src += 1024; dma_dst += 1024; --dma_left;
+      }
+    }
+  };
   auto wrap_seq = [&](int s) { return s >= NS ? s - NS : s; };
   issue(0, 0);
   issue(wrap_seq(1), BF_CHUNK_BYTES);
@@ -225,13 +248,20 @@ __device__ __forceinline__ void sampler_bf16_body(const KArgs& a) {
   // start of a chunk's use: its DMA has landed (all but the two newer chunks' 8 DMAs of this wave are done), every
   // wave is past the previous chunk (barrier), so that chunk's slot can take the chunk three ahead.
   auto next_chunk = [&]() -> const char* {
+    if constexpr (SPREAD) { sfor<PPW>([&](auto) { dma_tick(); }); }     // the previous refill's remainder, before the wait counts it
 #if !defined(FRL_BF_EXP_NOBAR)   // (timing experiments only: results are wrong without the wait / barrier / DMA)
     if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
 #if !defined(FRL_BF_EXP_NODMA)
-    issue(seq_issue, boff_issue);
+    if constexpr (SPREAD) {
+      dma_src = img + (size_t)seq_issue * BF_CHUNK_BYTES;
+      dma_dst = smem + boff_issue + wave * (PPW * 1024);
+      dma_left = PPW;
+    } else {
+      issue(seq_issue, boff_issue);
+    }
 #endif
     seq_issue = (seq_issue + 1 == NS) ? 0 : seq_issue + 1;
     boff_issue = (boff_issue + BF_CHUNK_BYTES) & (BF_NBUF * BF_CHUNK_BYTES - 1);
@@ -287,14 +317,14 @@ __device__ __forceinline__ void sampler_bf16_body(const KArgs& a) {
           constexpr int ks = decltype(KI)::value;
           if constexpr (ks < NXK) return bx[ks]; else return cbp[ks - NXK];
         };
-        layer_bf<ACT, K0, NOB>(bin, b0, s_tb + j * H, next_chunk, lane16, ls);
+        layer_bf<ACT, K0, NOB>(bin, b0, s_tb + j * H, next_chunk, dma_tick, lane16, ls);
       }
       FRL_TMARK(2)
 
       // ---------------- hidden Dense_l : h_l = act(b_l + W_l^T h_{l-1}) -------------------------------
       for (int l = 1; l < a.L; ++l) {
         auto bh = [&](auto KI) -> u32x4 { return bin[decltype(KI)::value]; };
-        layer_bf<ACT, NKH, NOB>(bout, bh, s_bh + (l - 1) * H, next_chunk, lane16, ls);
+        layer_bf<ACT, NKH, NOB>(bout, bh, s_bh + (l - 1) * H, next_chunk, dma_tick, lane16, ls);
         sfor<NKH>([&](auto KI) { constexpr int k = decltype(KI)::value; bin[k] = bout[k]; });
       }
       FRL_TMARK(3)
@@ -323,6 +353,7 @@ __device__ __forceinline__ void sampler_bf16_body(const KArgs& a) {
         sfor<NKH>([&](auto KI) {
           constexpr int ks = decltype(KI)::value;
           O = mfma_bf(awl[ks & 3], bin[ks], O);
+          if constexpr (ks % FRL_BF_TICK == 0) dma_tick();
           if constexpr (ks + 4 < NKH) awl[ks & 3] = *(const u32x4*)(sl + (ks + 4) * 1024);
         });
       }
@@ -348,28 +379,7 @@ __device__ __forceinline__ void sampler_bf16_body(const KArgs& a) {
           a.xt_hist[o] = xt;
           a.eps_hist[o] = eps;
         }
-        float xn;
-        if (a.mode == MODE_DDPM_DDPM) {
-          float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
-          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);   // ddpm.py:200-201
-          xn = c2 * (c3 * x0h + c4 * xt);                           // ddpm.py:202-203
-          xn += c5 * z;                                             // ddpm.py:206
-        } else if (a.mode == MODE_DDPM_DDIM) {
-          xn = c0 * (xt - c1 * eps) + c2 * eps;                     // ddpm.py:211
-          if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
-        } else if (a.mode == MODE_CDDPM_DDPM) {
-          float x0h = (xt - c1 * eps) / c0;                         // continuous_ddpm.py:165
-          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
-          xn = c2 * x0h + c3 * xt;                                  // :173
-          xn += c5 * z;                                             // :174
-        } else if (a.mode == MODE_CDDPM_DDIM) {
-          float x0h = (xt - c1 * eps) / c0;
-          if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
-          xn = c2 * x0h + c3 * eps;                                 // :177
-        } else {
-          xn = xt + eps / c0;                                       // cnf.py:108
-          if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
-        }
+        const float xn = bf_solver_update(a.mode, a.clip, a.x_min, a.x_max, c0, c1, c2, c3, c4, c5, xt, eps, z);
         xs[r] = in ? xn : 0.0f;
       });
     }

@@ -346,28 +346,7 @@ frl_bwd_sweep_bf16_kernel(const BArgs b) {
             a.xt_hist[o] = xt;
             a.eps_hist[o] = eps;
           }
-          float xn;
-          if (a.mode == MODE_DDPM_DDPM) {
-            float x0h = c0 * (xt - c1 * eps);                       // ddpm.py:199
-            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);   // ddpm.py:200-201
-            xn = c2 * (c3 * x0h + c4 * xt);                           // ddpm.py:202-203
-            xn += c5 * z;                                             // ddpm.py:206
-          } else if (a.mode == MODE_DDPM_DDIM) {
-            xn = c0 * (xt - c1 * eps) + c2 * eps;                     // ddpm.py:211
-            if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
-          } else if (a.mode == MODE_CDDPM_DDPM) {
-            float x0h = (xt - c1 * eps) / c0;                         // continuous_ddpm.py:165
-            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
-            xn = c2 * x0h + c3 * xt;                                  // :173
-            xn += c5 * z;                                             // :174
-          } else if (a.mode == MODE_CDDPM_DDIM) {
-            float x0h = (xt - c1 * eps) / c0;
-            if (a.clip) x0h = fminf(fmaxf(x0h, a.x_min), a.x_max);
-            xn = c2 * x0h + c3 * eps;                                 // :177
-          } else {
-            xn = xt + eps / c0;                                       // cnf.py:108
-            if (a.clip) xn = fminf(fmaxf(xn, a.x_min), a.x_max);
-          }
+          const float xn = bf_solver_update(a.mode, a.clip, a.x_min, a.x_max, c0, c1, c2, c3, c4, c5, xt, eps, z);
           xs[r] = in ? xn : 0.0f;
         });
       } else {
