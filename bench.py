@@ -230,8 +230,8 @@ STRONG_TOTAL_STATES = {"cfg3": 8388608, "cfg4": 65536}
 TRAFFIC_PROFILES = {
     "cfg1": ("profiles/r02_prof_cfg1/pmc_summary.json", "frl_sampler_lat_kernel"),
     "cfg2": ("profiles/r03_prof_cfg2/pmc_summary.json", "frl_sampler_rs_kernel"),
-    "cfg3": ("profiles/r02_prof_cfg3/pmc_summary.json", "frl_sampler_rs_kernel"),
-    "cfg4": ("profiles/r02_prof_cfg4/pmc_summary.json", "frl_sampler_rs_kernel"),
+    "cfg3": ("profiles/r03_prof_cfg3/pmc_summary.json", "frl_sampler_rs_kernel"),
+    "cfg4": ("profiles/r03_prof_cfg4/pmc_summary.json", "frl_sampler_rs_kernel"),
     "res_dac": ("profiles/r02_prof_res_dac/pmc_summary.json", "frl_sampler_res_kernel"),
 }
 
