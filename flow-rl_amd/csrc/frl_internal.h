@@ -87,6 +87,7 @@ inline int plan_layout(const FrlDesc& d, Plan& p, int flags = PLAN_HOIST, int fo
 inline bool plan_two_wave_shape(const FrlDesc& d, const Plan& p) {
   if (d.dtype != FRL_DTYPE_F32 || d.backbone != FRL_BACKBONE_MLP || p.H != 256 || d.layer_norm != 0) return false;     // in-kernel draws: the keyed variant of the build (EXT 6)
   if (d.kind != FRL_KIND_CNF && d.solver != FRL_SOLVER_DDPM && d.solver != FRL_SOLVER_DDIM) return false;
+  if (d.rng_impl != FRL_RNG_NONE && 16 * p.A > 64) return false;   // keyed variant: a tile's 16 x A draws, one per lane
   if (d.tile_policy != FRL_TILE_AUTO && d.tile_policy != FRL_TILE_THROUGHPUT) return false;
   if (d.cond_embed) return false;
   return !(p.A > 16 || p.C > 48 || (d.particles >= 4 && p.C >= 32));

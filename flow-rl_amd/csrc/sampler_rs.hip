@@ -60,7 +60,8 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
 //      3 = 1 + critic scoring and best-of-N selection on the finished tile (CriticTab, frl_internal.h), 4 = 3 with a relu critic,
 //      5 = 1 + in-kernel threefry draws as micro-steps behind the MFMAs of the first hidden layer (no LayerNorm code: its
 //          presence alone costs the hot loops ~4 % in accumulator moves; LayerNorm + draws = EXT 2, draws up front)
-//      6 = 0 + the same micro-step draws (the two-wave build's keyed variant: nothing of EXT 1, so that it fits 256 registers)
+//      6 = 0 + micro-step draws, ONE dense draw per lane and step (the two-wave build's keyed variant, x_dim <= 4: nothing of
+//          EXT 1, so that it fits 256 registers)
 template <int TR, int H, int ACT, int NRX, int CKMAX, int EXTV>
 __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab& ct) {
   typedef Geo<TR> G;
@@ -100,6 +101,12 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
   const bool zrow_lds = EXT != 0 && a.state_bias != nullptr && (a.particles % TR) == 0;
   float* s_zrow = s_coef + a.NE * COEF_STRIDE;
   float* s_ln = s_zrow + (zrow_lds ? nw * H : 0);     // EXT 2, LayerNorm backbones only: [L][2][H] scale | bias rows
+  // EXT 6 (keyed two-wave build): when a tile's TR * A draws fit one per lane, ONE dense draw per lane and step replaces the NRX
+  // per-register draws (at x_dim 3 only 3 of a chain's 16 register rows exist: 48 of 256 draws were used); the values go to
+  // their owner lanes through 64 wave-private floats of LDS (the EXT 6 build has no hoisted row / LayerNorm / critic tables here)
+  // The plan sends a keyed call to this build only when TR * A <= 64 (plan_two_wave_shape), so it carries no per-register variant.
+  constexpr bool DENSE = (EXTV == 6);
+  float* s_zd = s_zrow + wave * 64;
   if constexpr (HAS_LN) {
     if (a.ws_ln != nullptr)
       for (int idx = tid; idx < a.L * 2 * H; idx += blockDim.x) s_ln[idx] = a.ws_ln[idx];
@@ -305,6 +312,11 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
           });
         }
       }
+      auto rng_slot_dense = [&](auto MI) __attribute__((always_inline)) {     // micro-step mm of the lane's ONE dense draw: element
+        constexpr int mm = decltype(MI)::value;                               // lane of the tile's TR x A block of normal(key_j, (B, A))
+        rng_micro<mm>(rd, rk0, rk1, a.rng_impl, (unsigned long long)a.rng_total * a.A, (unsigned long long)(a.rng_off + chain - li) * a.A + lane);
+        if constexpr (mm == 11) s_zd[lane] = rd.p;
+      };
       auto rng_slot = [&](auto MI) __attribute__((always_inline)) {     // micro-step m of the step's NRX draws
         constexpr int m = decltype(MI)::value, r = m / 12, mm = m % 12;
         const int ai = G::rowr(r) + 4 * ls;
@@ -362,7 +374,8 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
 
       // ---------------- hidden Dense_l : Q = b_l + W_l^T act(P) ; P <- Q ----------------------------
       auto hidden_layer = [&](const int l, auto RNG_T) __attribute__((always_inline)) {
-        constexpr bool with_rng = decltype(RNG_T)::value;
+        constexpr int rng_mode = (int)decltype(RNG_T)::value;       // 0 no draws, 1 one draw per x register, 2 one dense draw per lane
+        constexpr bool with_rng = rng_mode != 0;
         // operands of this layer's first RING-1 k-steps are already in flight; the tail prefetches the next
         // layer's — after the last hidden layer that is the FIRST hidden layer of the next evaluation (next step /
         // critic member / tile)
@@ -394,7 +407,8 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
               bn1 = y[0]; bn2 = y[1];
             }
             constexpr int NSLOT = 4 * NG;       // MFMAs per k-step
-            constexpr bool rng_here = with_rng && (k & 1) == 0 && k >= 2 && ((k - 2) / 2) * NSLOT < 12 * NRX;
+            constexpr int NMICRO = (rng_mode == 2) ? 12 : 12 * NRX;
+            constexpr bool rng_here = with_rng && (k & 1) == 0 && k >= 2 && ((k - 2) / 2) * NSLOT < NMICRO;
             sfor<NG>([&](auto GI) {
               constexpr int g = decltype(GI)::value;
               const f32x4 aw = ring[k % RING][g];
@@ -403,7 +417,10 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
                 Q[g * 4 + jj] = G::mfma(aw[jj], bop, Q[g * 4 + jj]);
                 if constexpr (rng_here) {
                   constexpr int m = ((k - 2) / 2) * NSLOT + g * 4 + jj;
-                  if constexpr (m < 12 * NRX) rng_slot(std::integral_constant<int, m>{});
+                  if constexpr (m < NMICRO) {
+                    if constexpr (rng_mode == 2) rng_slot_dense(std::integral_constant<int, m>{});
+                    else rng_slot(std::integral_constant<int, m>{});
+                  }
                   if constexpr (g * 4 + jj > 0) __builtin_amdgcn_sched_barrier(0);     // MFMA i, then micro-step i: as written
                 }
               });
@@ -421,8 +438,19 @@ __device__ __forceinline__ void sampler_rs_body(const KArgs& a, const CriticTab&
         if constexpr (HAS_LN) { if (a.ws_ln != nullptr) ln_pass(P, s_ln + l * 2 * H); }
       };
       if constexpr (HAS_RNG) {
-        if (Lj > 1) hidden_layer(1, std::true_type{});
+        if (Lj > 1) hidden_layer(1, std::integral_constant<int, DENSE ? 2 : 1>{});
         for (int l = 2; l < Lj; ++l) hidden_layer(l, std::false_type{});
+        if constexpr (DENSE) {
+          if (Lj > 1) {       // the dense draws back to their owners (same wave wrote them: LDS operations of a wave stay in order)
+            sfor<NRX>([&](auto RI) {
+              constexpr int r = decltype(RI)::value;
+              const int ai = G::rowr(r) + 4 * ls;
+              const bool own = rused && valid && ai < a.A;
+              const float zv = s_zd[own ? li * a.A + ai : 0];
+              zr[r] = own ? zv : 0.0f;
+            });
+          }
+        }
       } else {
         for (int l = 1; l < Lj; ++l) hidden_layer(l, std::false_type{});
       }
@@ -619,6 +647,7 @@ static int launch_kern(const void* kern, const char* tag, size_t* configured, in
   const size_t lds = sizeof(float) * ((size_t)a.NE * H + (size_t)(a.L - 1) * H + LAST_PAD + (size_t)a.NE * COEF_STRIDE +
                                       (a.ws_ln != nullptr ? (size_t)a.L * 2 * H : 0) +
                                       ((a.state_bias != nullptr && a.particles % TR == 0) ? (size_t)nw * H : 0) +
+                                      ((a.rng_impl != FRL_RNG_NONE && TR == 16 && H == 256) ? (size_t)nw * 64 : 0) +     // keyed two-wave build: dense draws
                                       (ct != nullptr ? (size_t)ct->E * ((size_t)ct->L * H + LAST_PAD) : 0));
   if (lds > 160 * 1024) { set_error("sampler: %d network evaluations per chain need %zu B of LDS (> 160 KiB)", a.NE, lds); return FRL_EUNSUPPORTED; }
   int dev = 0;
@@ -652,7 +681,8 @@ template <int ACT>
 static int launch_w2(const KArgs& a, hipStream_t stream) {
   if constexpr (ACT == FRL_ACT_IDENTITY) { set_error("two-wave build: no identity-activation unit"); return FRL_EINVAL; }
   else {
-    if (a.ws_ln != nullptr || a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.AR > 4 || a.CK > 12) {
+    if (a.ws_ln != nullptr || a.mode > MODE_CNF_EULER || a.state_bias != nullptr || a.AR > 4 || a.CK > 12 ||
+        (a.rng_impl != FRL_RNG_NONE && 16 * a.A > 64)) {
       set_error("two-wave build asked for a path it does not carry (plan / launch mismatch)"); return FRL_EINVAL; }
     static thread_local size_t configured[2][16] = {{0}, {0}};
     char tag[64];

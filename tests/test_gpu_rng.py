@@ -144,8 +144,8 @@ def _t(a):
 
 @pytest.mark.parametrize("impl", IMPLS)
 def test_sampler_with_key_two_wave_build(impl):
-    """Large plain 256-wide batches take the 16-chain two-wave build; with a key its EXT 6 variant (micro-step draws, the
-    other wave's MFMAs beside them).  Same checks as above at 70 001 chains (a ragged last tile): the kernel fed
+    """Large plain 256-wide batches take the 16-chain two-wave build; with a key (and x_dim <= 4) its EXT 6 variant (one dense
+    draw per lane and step as micro-steps, the other wave's MFMAs beside them, values to their owner lanes through LDS).  Same checks as above at 70 001 chains (a ragged last tile): the kernel fed
     frl_random_normal's tensor for the oracle's iteration keys, and the float64 oracle on a slice."""
     import torch
     import flowrl_hip as fh
@@ -167,6 +167,26 @@ def test_sampler_with_key_two_wave_build(impl):
     e0, ex, ee = H.rel_err(x0[sl], ref0), H.rel_err(xh[:, sl], refx), H.rel_err(eh[:, sl], refe)
     print(f"two-wave keyed/{impl}: vs oracle x0 {e0:.2e} xt_hist {ex:.2e} eps_hist {ee:.2e}")
     assert e0 <= 1e-4 and ex <= 1e-4 and ee <= 1e-4
+
+
+def test_keyed_wide_action_stays_on_32_chain_tiles():
+    """The keyed two-wave build draws ONE element per lane (16 x x_dim <= 64); a wider action takes a 32-chain build at
+    any batch size, and agrees with the tensor-fed call (which does take the two-wave build)."""
+    import torch
+    import flowrl_hip as fh
+    import flowrl_hip.random as fr
+    impl = IMPLS[0]
+    case = H.Case("ddpm-a6-large", "ddpm", A=6, S=11, T=4, B=66000, seed=22)
+    params, xT, cond, noise, x0, xh, eh = _run_with_key(case, impl, seed=77)
+    assert "kernel_w2" not in fh.last_kernels(), fh.last_kernels()     # a 32-chain build (EXT 5 or the latency kernel: per-register draws)
+    keys, _ = tf.sampler_key_chain(case.kind, case.solver, case.T, tf.prng_key(77), impl)
+    model = H.product_model(case, params)
+    dn = torch.stack([fr.normal(_t(keys[j]), xT.shape, impl) for j in range(case.T)])
+    _, y0, (yh, _) = model.sample(None, _t(xT), _t(cond), False, case.solver, noise=dn, history=True)
+    torch.cuda.synchronize()
+    assert "kernel_w2" in fh.last_kernels(), fh.last_kernels()
+    d0, dx = H.rel_err(x0, y0.cpu().numpy()), H.rel_err(xh, yh.cpu().numpy())
+    assert d0 <= 1e-4 and dx <= 1e-4, f"x0 {d0:.2e}, xt_hist {dx:.2e}"    # two different builds: another f32 summation order, not 2e-6
 
 
 def test_explicit_noise_wins_and_rng_still_advances():
