@@ -15,5 +15,7 @@ timeout -k 10 200 python bench.py --rng partitionable --no-cpu-baseline > gpurun
 timeout -k 10 300 python bench.py --workload cfg4 --rng partitionable --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_keyed.json 2>/dev/null || exit 12
 timeout -k 10 300 python bench.py --workload cfg4 --select fused --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_select_fused.json 2>/dev/null || exit 13
 timeout -k 10 300 python bench.py --workload cfg4 --select separate --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_select_separate.json 2>/dev/null || exit 14
+timeout -k 10 300 python bench.py --workload cfg3 --dtype bf16 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/final/cfg3_bf16.json 2>/dev/null || exit 16
+timeout -k 10 300 python bench.py --workload cfg4 --dtype bf16 --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/final/cfg4_bf16.json 2>/dev/null || exit 17
 timeout -k 10 200 bench/native_bench > gpurun_out/final/native_cfg2.json 2>/dev/null || exit 15
 echo done
