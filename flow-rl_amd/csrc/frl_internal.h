@@ -491,9 +491,10 @@ inline bool sampler_lat_supports(const KArgs& a) {
   return (a.H == 256 || a.H == 512) && ((ar <= 4 && ck <= 12) || (ar <= 12 && ck <= 64)) && a.XR >= 2 * ar &&
          lat_lds_bytes(a.NE, a.L, a.H, false, a.ws_ln != nullptr) <= 160 * 1024;
 }
-// the 16-chain-tile build (MFMA 16x16x4): x rows ROWR(n) + 4 s of four k-steps cover 16 action rows; cond k-steps of 4 rows
+// the 16-chain-tile build (MFMA 16x16x4): x rows ROWR(n) + 4 s of four k-steps cover 16 action rows (eight: 32, with two
+// Dense_L output tiles); cond k-steps of 4 rows
 inline bool sampler_lat16_supports(const KArgs& a) {
-  return a.H == 256 && a.A <= 16 && (a.C + 3) / 4 <= 32 && lat_lds_bytes(a.NE, a.L, a.H, false, a.ws_ln != nullptr) <= 160 * 1024;
+  return a.H == 256 && a.A <= 32 && (a.C + 3) / 4 <= 32 && lat_lds_bytes(a.NE, a.L, a.H, false, a.ws_ln != nullptr) <= 160 * 1024;
 }
 int launch_prepare_bf16(const FrlParams& p, const Plan& pl, float* ws, hipStream_t stream);   // bf16 weight stream image
 int launch_sampler_bf16(const FrlDesc& d, const KArgs& a, hipStream_t stream);                 // bf16 MFMA variant (H = 256 or 512)

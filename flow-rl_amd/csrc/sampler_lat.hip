@@ -57,7 +57,8 @@ frl_sampler_lat_kernel(const KArgs a) {
   constexpr int NBW = H / (4 * TR); // TR-row output blocks per wave
   constexpr int FW = H / 4;         // features per wave
   constexpr int NK = H / KS;        // k-steps per hidden layer
-  static_assert(NBW % KS == 0 && NRX <= NR, "geometry");
+  constexpr int NOT = (NRX + NR - 1) / NR;   // TR-row output tiles of Dense_L: two only on 16-chain tiles with x_dim > 16 (DACER / QVPO humanoid: 17)
+  static_assert(NBW % KS == 0 && NRX <= 2 * NR && (!STASH || NOT == 1), "geometry");
   constexpr int ROWB = H * 4;
   constexpr int RW = (TR == 16) ? 32 : 16;   // hidden-layer weight ring (k-steps ahead): lookahead of ~2000 MFMA cycles either way
   constexpr int N0 = NRX + CKMAX;            // Dense_0 k-step slots
@@ -107,15 +108,18 @@ frl_sampler_lat_kernel(const KArgs a) {
   constexpr int PSTEP = (TR == 32) ? 2 : 1;
 
   // Dense_L operands stay resident: k-step (jb, r) contracts feature FW w + NBW (ROWR(r) + 4 ls) + jb, lane i = output row
-  float wl[NBW][NR];
+  float wl[NOT][NBW][NR];
   {
     const float* WL = a.wl_raw;
-    sfor<NBW>([&](auto JI) {
-      constexpr int jb = decltype(JI)::value;
-      sfor<NR>([&](auto RI) {
-        constexpr int r = decltype(RI)::value;
-        const int f = FW * wave + NBW * (G::rowr(r) + 4 * ls) + jb;
-        wl[jb][r] = (li < a.AO) ? WL[(size_t)f * a.AO + li] : 0.0f;
+    sfor<NOT>([&](auto TI) {
+      constexpr int t = decltype(TI)::value;
+      sfor<NBW>([&](auto JI) {
+        constexpr int jb = decltype(JI)::value;
+        sfor<NR>([&](auto RI) {
+          constexpr int r = decltype(RI)::value;
+          const int f = FW * wave + NBW * (G::rowr(r) + 4 * ls) + jb;
+          wl[t][jb][r] = (t * TR + li < a.AO) ? WL[(size_t)f * a.AO + t * TR + li] : 0.0f;
+        });
       });
     });
   }
@@ -315,8 +319,8 @@ frl_sampler_lat_kernel(const KArgs a) {
       sfor<R0 - 1>([&](auto NI) { l0load(NI); });   // next evaluation's (or tile's) Dense_0 operands
 
       // ---------------- Dense_L, split-K over the waves ------------------------------------------------------
-      acc_t O;
-      sfor<NR>([&](auto RI) { O[decltype(RI)::value] = 0.0f; });
+      acc_t O[NOT];
+      sfor<NOT>([&](auto TI) { sfor<NR>([&](auto RI) { O[decltype(TI)::value][decltype(RI)::value] = 0.0f; }); });
       if constexpr (STASH) {
         sfor<NBW>([&](auto JI) {
           constexpr int jb = decltype(JI)::value;
@@ -327,8 +331,8 @@ frl_sampler_lat_kernel(const KArgs a) {
             act_grad2<ACT>(f32x2{acc[jb][rp], acc[jb][rp + PSTEP]}, h, d);
             st2(h, rs_hd, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
             st2(d, rs_ad, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
-            O = G::mfma(wl[jb][rp], h[0], O);
-            O = G::mfma(wl[jb][rp + PSTEP], h[1], O);
+            O[0] = G::mfma(wl[0][jb][rp], h[0], O[0]);
+            O[0] = G::mfma(wl[0][jb][rp + PSTEP], h[1], O[0]);
           });
         });
       } else {
@@ -336,19 +340,26 @@ frl_sampler_lat_kernel(const KArgs a) {
         constexpr int jb = decltype(JI)::value;
         sfor<NR>([&](auto RI) {
           constexpr int r = decltype(RI)::value;
-          O = G::mfma(wl[jb][r], act_fn<ACT>(acc[jb][r]), O);
+          const float hv = act_fn<ACT>(acc[jb][r]);
+          sfor<NOT>([&](auto TI) { constexpr int t = decltype(TI)::value; O[t] = G::mfma(wl[t][jb][r], hv, O[t]); });
         });
       });
       }
       {
         float* part = s_act + (phase++ & 1) * (H * TR);
-        sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; part[(wave * NR + r) * 64 + lane] = O[r]; });
+        sfor<NOT>([&](auto TI) {
+          constexpr int t = decltype(TI)::value;
+          sfor<NR>([&](auto RI) { constexpr int r = decltype(RI)::value; part[((t * 4 + wave) * NR + r) * 64 + lane] = O[t][r]; });
+        });
         __syncthreads();
-        sfor<NR>([&](auto RI) {
-          constexpr int r = decltype(RI)::value;
-          float s = s_bl[G::rowr(r) + 4 * ls];
-          sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; s += part[(w * NR + r) * 64 + lane]; });
-          O[r] = s;
+        sfor<NOT>([&](auto TI) {
+          constexpr int t = decltype(TI)::value;
+          sfor<NR>([&](auto RI) {
+            constexpr int r = decltype(RI)::value;
+            float s = s_bl[t * TR + G::rowr(r) + 4 * ls];
+            sfor<4>([&](auto WI) { constexpr int w = decltype(WI)::value; s += part[((t * 4 + w) * NR + r) * 64 + lane]; });
+            O[t][r] = s;
+          });
         });
       }
 
@@ -361,7 +372,7 @@ frl_sampler_lat_kernel(const KArgs a) {
         constexpr int r = decltype(RI)::value;
         const int ai = G::rowr(r) + 4 * ls;
         const bool in = valid && ai < a.A;
-        const float eps = O[r], xt = xs[r];
+        const float eps = O[r / NR][r % NR], xt = xs[r];
         if (a.xt_hist != nullptr && in && c6 == 0.0f && wave == 0) {
           const int jh = (a.mode == MODE_CDDPM_DPM2) ? j >> 1 : j;
           const long long o = ((long long)jh * a.B + chain) * a.A + ai;
@@ -457,7 +468,7 @@ int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
     else {
       if (a.H != 256 || !can32 || a.stash_a == nullptr || a.ws_ln != nullptr || a.NE != a.T) { set_error("latency training forward: unsupported configuration (H %d, evaluations %d / steps %d)", a.H, a.NE, a.T); return FRL_EUNSUPPORTED; }
       // 16-chain tiles while they still give every CU at most one tile (the forward's own rule): half the latency per tile
-      if (tile_rows != 32 && can16 && 2 * ((a.B + 31) / 32) <= ncu)
+      if (tile_rows != 32 && can16 && a.A <= 16 && 2 * ((a.B + 31) / 32) <= ncu)
         return (a.C + 3) / 4 <= 12 ? launch_lat_inst<16, 256, ACT, 4, 12, true>(a, ncu, stream) : launch_lat_inst<16, 256, ACT, 4, 32, true>(a, ncu, stream);
       const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;
       if (narrow) return launch_lat_inst<32, 256, ACT, 4, 12, true>(a, ncu, stream);
@@ -469,6 +480,7 @@ int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
   if (use16 ? !can16 : !can32) { set_error("latency sampler: no %d-chain-tile build for this configuration (H %d, x_dim %d, operand cond rows %d)", use16 ? 16 : 32, a.H, a.A, a.C); return FRL_EUNSUPPORTED; }
   if (use16) {
     const bool narrow = (a.C + 3) / 4 <= 12;
+    if (a.A > 16) return launch_lat_inst<16, 256, ACT, 8, 32>(a, ncu, stream);     // x_dim 17 .. 32: two Dense_L output tiles
     return narrow ? launch_lat_inst<16, 256, ACT, 4, 12>(a, ncu, stream) : launch_lat_inst<16, 256, ACT, 4, 32>(a, ncu, stream);
   }
   const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;

@@ -67,7 +67,7 @@ extern "C" {
 #define FRL_TILE_THROUGHPUT 1 /* one wave per tile, no barriers (csrc/sampler_rs.hip): large batches */
 #define FRL_TILE_LATENCY 2    /* four waves per tile, features split over the SIMDs (csrc/sampler_lat.hip): acting */
 #define FRL_TILE_LATENCY_32 3 /* the latency build on 32-chain tiles (MFMA 32x32x2)                                  */
-#define FRL_TILE_LATENCY_16 4 /* the latency build on 16-chain tiles (MFMA 16x16x4): x_dim <= 16, H = 256; LATENCY picks it
+#define FRL_TILE_LATENCY_16 4 /* the latency build on 16-chain tiles (MFMA 16x16x4): x_dim <= 32, H = 256; LATENCY picks it
                                  while ceil(B / 16) <= CUs                                                           */
 
 /* Where the per-step N(0, I) draws of the ddpm solvers come from (FrlDesc.rng_impl).  The reference draws them with
