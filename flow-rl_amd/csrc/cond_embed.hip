@@ -149,6 +149,106 @@ frl_state_bias_kernel(const float* __restrict__ obs, long long n_states, int S, 
   }
 }
 
+// ---- the same two kernels with the FEATURES split over waves -------------------------------------------------------------
+// Above, one wave carries all 128 features of its 32 states: four MFMAs per k-step behind one 16-byte load, S / 2 dependent
+// k-steps — 65 .. 150 us however few states there are (an acting call has ONE), because a call of n states runs n / 32 waves.
+// Here a wave owns ONE of the four 32x32 tiles (features 4 i + j of its group): one MFMA per k-step, operands prefetched 32
+// k-steps ahead in registers, four (cond_embed) or H / 32 (state bias) times as many waves.  Per output element the k order and
+// the instruction are those of the kernels above, so the results are the same bits; the launchers take these up to 32768 states.
+constexpr int CE_CHUNK = 32;    // k-steps per prefetch chunk (two register buffers)
+constexpr long long CE_WIDE_MAX_STATES = 32768;
+
+// acc <- acc + sum over k-steps [0, nk) of A[k][col] * bop(k), one MFMA per k-step, in k order.
+//   wload(s): this lane's A operand of k-step s; bload(s): its B operand.  Both may be called for s >= nk (must return 0 / be safe).
+template <typename WLoad, typename BLoad>
+__device__ __forceinline__ f32x16 ce_contract(f32x16 acc, int nk, WLoad&& wload, BLoad&& bload) {
+  float wa[2][CE_CHUNK], ba[2][CE_CHUNK];
+  cfor<CE_CHUNK>([&](auto I) { constexpr int i = decltype(I)::value; wa[0][i] = wload(i); ba[0][i] = bload(i); });
+  for (int c = 0; c * CE_CHUNK < nk; c += 2) {
+    cfor<CE_CHUNK>([&](auto I) { constexpr int i = decltype(I)::value; wa[1][i] = wload((c + 1) * CE_CHUNK + i); ba[1][i] = bload((c + 1) * CE_CHUNK + i); });
+    cfor<CE_CHUNK>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if (c * CE_CHUNK + i < nk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][i], ba[0][i], acc, 0, 0, 0);
+    });
+    cfor<CE_CHUNK>([&](auto I) { constexpr int i = decltype(I)::value; wa[0][i] = wload((c + 2) * CE_CHUNK + i); ba[0][i] = bload((c + 2) * CE_CHUNK + i); });
+    cfor<CE_CHUNK>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if ((c + 1) * CE_CHUNK + i < nk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][i], ba[1][i], acc, 0, 0, 0);
+    });
+  }
+  return acc;
+}
+
+// grid (H / 32, state tiles of 32), one wave per block: feature block fb = 4 g + j <-> features 128 g + 4 i + j
+__global__ void __launch_bounds__(64)
+frl_state_bias_wide_kernel(const float* __restrict__ obs, long long n_states, int S, int H, const float* w, const float* b,
+                           float* __restrict__ zs) {
+  const int ROWB = H * 4;
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const int g = blockIdx.x >> 2, j = blockIdx.x & 3;
+  const long long state = (long long)blockIdx.y * 32 + li;
+  const bool valid = state < n_states;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, S * ROWB, 0x00020000);
+  const int nk = (S + 1) / 2;
+  const float* orow = obs + (valid ? state : 0) * S;
+  f32x16 acc;
+  cfor<16>([&](auto RI) {
+    constexpr int r = decltype(RI)::value;
+    acc[r] = (b != nullptr) ? b[128 * g + 4 * (CE_ROWR(r) + 4 * lh) + j] : 0.0f;
+  });
+  const unsigned voff = (unsigned)(lh * ROWB + 512 * g + li * 16 + j * 4);
+  acc = ce_contract(acc, nk,
+      [&](int s) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, s * 2 * ROWB, 0)); },   // rows >= S: zero (descriptor bounds)
+      [&](int s) { const int k = 2 * s + lh; return (valid && k < S) ? orow[k] : 0.0f; });
+  if (valid) {
+    float* zrow = zs + state * H + 128 * g;
+    cfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; zrow[4 * (CE_ROWR(r) + 4 * lh) + j] = acc[r]; });
+  }
+}
+
+// grid = state tiles of 32, four waves per block: wave j owns features 4 i + j of both layers; layer 1 reaches layer 2 through LDS
+__global__ void __launch_bounds__(256)
+frl_cond_embed_wide_kernel(int act, const float* __restrict__ obs, long long n_states, int S, const float* w0, const float* b0,
+                           const float* w1, const float* b1, float* __restrict__ cfeat) {
+  constexpr int E = COND_EMBED_DIM, ROWB = E * 4;
+  __shared__ float s_h[E * 32];          // [feature][state of the tile]
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int j = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long state = (long long)blockIdx.x * 32 + li;
+  const bool valid = state < n_states;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)w0, 0, S * ROWB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)w1, 0, E * ROWB, 0x00020000);
+  const int nk = (S + 1) / 2;
+  const float* orow = obs + (valid ? state : 0) * S;
+  // ---- layer 1 (k order and operands of frl_cond_embed_kernel's tile j) ----
+  f32x16 acc;
+  cfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; acc[r] = b0[4 * (CE_ROWR(r) + 4 * lh) + j]; });
+  const unsigned voff0 = (unsigned)(lh * ROWB + li * 16 + j * 4);
+  acc = ce_contract(acc, nk,
+      [&](int s) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, voff0, s * 2 * ROWB, 0)); },
+      [&](int s) { const int k = 2 * s + lh; return (valid && k < S) ? orow[k] : 0.0f; });
+  cfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; s_h[(4 * (CE_ROWR(r) + 4 * lh) + j) * 32 + li] = cact(act, acc[r]); });
+  __syncthreads();
+  // ---- layer 2: k-step q = 16 jb + r contracts k = 4 (ROWR(r) + 4 lh) + jb, in that order (frl_cond_embed_kernel) ----
+  f32x16 out;
+  cfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; out[r] = b1[4 * (CE_ROWR(r) + 4 * lh) + j]; });
+  const unsigned voff1 = (unsigned)(lh * (16 * ROWB) + li * 16 + j * 4);
+  cfor<4>([&](auto BI) {
+    constexpr int jb = decltype(BI)::value;
+    float wv[16], hv[16];
+    cfor<16>([&](auto RI) {
+      constexpr int r = decltype(RI)::value;
+      wv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, voff1, (jb + 4 * CE_ROWR(r)) * ROWB, 0));
+      hv[r] = s_h[(4 * (CE_ROWR(r) + 4 * lh) + jb) * 32 + li];
+    });
+    cfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; out = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], hv[r], out, 0, 0, 0); });
+  });
+  if (valid) {
+    float* crow = cfeat + state * E;
+    cfor<16>([&](auto RI) { constexpr int r = decltype(RI)::value; crow[4 * (CE_ROWR(r) + 4 * lh) + j] = cact(act, out[r]); });
+  }
+}
+
 // ---- cond_embedding backward (DACER's actor loss differentiates the embedding too: dacer.py:141-162, ddpm.py:89-90) -----
 // activation and derivative in one go (the three activations the chain VJP supports)
 __device__ __forceinline__ void cact_grad(int act, float z, float& h, float& d) {
@@ -292,7 +392,8 @@ int launch_state_bias(const float* obs, long long n_states, int in_dim, int H, c
   if (H % 128 != 0) { set_error("state bias: width %d is not a multiple of 128", H); return FRL_EUNSUPPORTED; }
   const long long n_wt = (n_states + 31) / 32;
   const int grid = (int)((n_wt + 3) / 4);
-  hipLaunchKernelGGL(frl_state_bias_kernel, dim3(grid), dim3(256), 0, stream, obs, n_states, in_dim, H, w, b, zs);
+  if (n_states <= CE_WIDE_MAX_STATES) hipLaunchKernelGGL(frl_state_bias_wide_kernel, dim3(H / 32, (unsigned)n_wt), dim3(64), 0, stream, obs, n_states, in_dim, H, w, b, zs);
+  else hipLaunchKernelGGL(frl_state_bias_kernel, dim3(grid), dim3(256), 0, stream, obs, n_states, in_dim, H, w, b, zs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("state bias launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
@@ -303,7 +404,8 @@ int launch_cond_embed(int act, const float* obs, long long n_states, int in_dim,
   if (n_states <= 0) return FRL_OK;
   const long long n_wt = (n_states + 31) / 32;
   const int grid = (int)((n_wt + 3) / 4);
-  hipLaunchKernelGGL(frl_cond_embed_kernel, dim3(grid), dim3(256), 0, stream, act, obs, n_states, in_dim, w0, b0, w1, b1, cfeat);
+  if (n_states <= CE_WIDE_MAX_STATES) hipLaunchKernelGGL(frl_cond_embed_wide_kernel, dim3((unsigned)n_wt), dim3(256), 0, stream, act, obs, n_states, in_dim, w0, b0, w1, b1, cfeat);
+  else hipLaunchKernelGGL(frl_cond_embed_kernel, dim3(grid), dim3(256), 0, stream, act, obs, n_states, in_dim, w0, b0, w1, b1, cfeat);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("cond_embed launch: %s", hipGetErrorString(e)); return FRL_EHIP; }
   return FRL_OK;
