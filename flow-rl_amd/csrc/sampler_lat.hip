@@ -58,7 +58,7 @@ frl_sampler_lat_kernel(const KArgs a) {
   constexpr int FW = H / 4;         // features per wave
   constexpr int NK = H / KS;        // k-steps per hidden layer
   constexpr int NOT = (NRX + NR - 1) / NR;   // TR-row output tiles of Dense_L: two only on 16-chain tiles with x_dim > 16 (DACER / QVPO humanoid: 17)
-  static_assert(NBW % KS == 0 && NRX <= 2 * NR && (!STASH || NOT == 1), "geometry");
+  static_assert(NBW % KS == 0 && NRX <= 2 * NR, "geometry");
   constexpr int ROWB = H * 4;
   constexpr int RW = (TR == 16) ? 32 : 16;   // hidden-layer weight ring (k-steps ahead): lookahead of ~2000 MFMA cycles either way
   constexpr int N0 = NRX + CKMAX;            // Dense_0 k-step slots
@@ -331,8 +331,11 @@ frl_sampler_lat_kernel(const KArgs a) {
             act_grad2<ACT>(f32x2{acc[jb][rp], acc[jb][rp + PSTEP]}, h, d);
             st2(h, rs_hd, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
             st2(d, rs_ad, voff_st, (a.L - 1) * 32768 + stash_off(jb, rp));
-            O[0] = G::mfma(wl[0][jb][rp], h[0], O[0]);
-            O[0] = G::mfma(wl[0][jb][rp + PSTEP], h[1], O[0]);
+            sfor<NOT>([&](auto TI) {
+              constexpr int t = decltype(TI)::value;
+              O[t] = G::mfma(wl[t][jb][rp], h[0], O[t]);
+              O[t] = G::mfma(wl[t][jb][rp + PSTEP], h[1], O[t]);
+            });
           });
         });
       } else {
@@ -468,8 +471,11 @@ int launch_sampler_lat_act(const KArgs& a0, int tile_rows, hipStream_t stream) {
     else {
       if (a.H != 256 || !can32 || a.stash_a == nullptr || a.ws_ln != nullptr || a.NE != a.T) { set_error("latency training forward: unsupported configuration (H %d, evaluations %d / steps %d)", a.H, a.NE, a.T); return FRL_EUNSUPPORTED; }
       // 16-chain tiles while they still give every CU at most one tile (the forward's own rule): half the latency per tile
-      if (tile_rows != 32 && can16 && a.A <= 16 && 2 * ((a.B + 31) / 32) <= ncu)
+      if (tile_rows != 32 && can16 && 2 * ((a.B + 31) / 32) <= ncu) {
+        if (a.A > 16)      // x_dim 17 .. 32 (DACER / QVPO humanoid): eight x k-steps, two Dense_L output tiles; cond rows hoisted (C = 0) or in the operand
+          return a.C == 0 ? launch_lat_inst<16, 256, ACT, 8, 1, true>(a, ncu, stream) : launch_lat_inst<16, 256, ACT, 8, 32, true>(a, ncu, stream);
         return (a.C + 3) / 4 <= 12 ? launch_lat_inst<16, 256, ACT, 4, 12, true>(a, ncu, stream) : launch_lat_inst<16, 256, ACT, 4, 32, true>(a, ncu, stream);
+      }
       const bool narrow = 4 * ((a.A + 7) / 8) <= 4 && (a.C + 1) / 2 <= 12;
       if (narrow) return launch_lat_inst<32, 256, ACT, 4, 12, true>(a, ncu, stream);
       // wide x with the condition rows hoisted per state (capi.hip launch_lat_train): no 64-register cond operand array
